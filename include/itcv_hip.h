@@ -1,0 +1,178 @@
+/*
+ * itcv_hip.h -- C ABI of libitcv_hip.so, the MI355X (gfx950) hot path of the Soft-Intro
+ * beta-TC-VAE training step.
+ *
+ * Every entry point takes plain device pointers, sizes and a HIP stream (as void*); no
+ * torch / C++ types cross this boundary.  All tensors are fp32, dense, NCHW.  Entry points
+ * return 0 on success and a non-zero code on error; itcv_last_error() returns the message
+ * of the last failure on the calling thread.  Nothing here allocates: scratch memory is
+ * passed in by the caller ("ws"), with the size given by the matching *_workspace() query.
+ * All launches are asynchronous on `stream`; nothing synchronises the device.
+ *
+ * The reference (meffmadd/intro-tc-vae) is pure Python/PyTorch, so there is no FFI layer to
+ * mirror; each entry point below names the reference call site (file:line under
+ * /root/reference) whose ATen work it replaces.  The Python mirror of the reference's
+ * module surface (models.py / ops.py / solvers) binds these with ctypes
+ * (intro-tc-vae_amd/hipvae/abi.py); see INTEGRATION.md.
+ */
+#ifndef ITCV_HIP_H
+#define ITCV_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ITCV_ABI_VERSION 1
+
+/* ---- library ------------------------------------------------------------------------- */
+int itcv_abi_version(void);
+const char* itcv_last_error(void);
+
+/* ---- convolution / linear: implicit GEMM on v_mfma_f32_32x32x2_f32 -------------------
+ * Stride 1, square odd kernel KS in {1,3,5}, zero padding KS/2 ("same"), groups 1.
+ * Replaces nn.Conv2d / nn.Linear forward+backward: models.py:28-47 (3x3 blocks), :213
+ * (5x5 stem), :290 (5x5 predict, with bias), :233 / :270 (Linear == KS 1, H=W=1).
+ *
+ * Weights are consumed in a packed, zero-padded K-major layout wp[Kp][Mp] (Kp = K rounded up
+ * to 16, Mp = M rounded up to 32):
+ *   for_dgrad = 0:  M = Co, K = Ci*KS*KS, wp[(ci*KK+tap)][co] = w[co][ci][tap]
+ *   for_dgrad = 1:  M = Ci, K = Co*KS*KS, wp[(co*KK+tap)][ci] = w[co][ci][KK-1-tap]
+ * so that the data-gradient is the same kernel run on dy with the roles of Ci/Co swapped. */
+size_t itcv_conv2d_packed_weight_elems(int Co, int Ci, int KS, int for_dgrad);
+int itcv_conv2d_pack_weight(const float* w, float* wp, int Co, int Ci, int KS, int for_dgrad,
+                            void* stream);
+/* y[B][Co][H][W] = conv(x[B][Ci][H][W], w) (+ bias[Co] if non-NULL).  `up2` != 0 reads x as the
+ * nearest-neighbour x2 upsampling of a [B][Ci][H/2][W/2] tensor (models.py:284-286 fused into the
+ * consumer). */
+size_t itcv_conv2d_fwd_workspace(int B, int Ci, int H, int W, int Co, int KS);
+int itcv_conv2d_fwd(const float* x, const float* wp, const float* bias, float* y, int B, int Ci,
+                    int H, int W, int Co, int KS, int up2, void* ws, size_t ws_bytes, void* stream);
+/* dw[Co][Ci][KS][KS] (+)= sum_{b,h,w} dy[b][co][h][w] * x[b][ci][h+kh-p][w+kw-p]; `up2` as in _fwd
+ * (x is the low-resolution [B][Ci][H/2][W/2] tensor, H/W are the dims of dy). */
+size_t itcv_conv2d_wgrad_workspace(int B, int Ci, int H, int W, int Co, int KS);
+int itcv_conv2d_wgrad(const float* x, const float* dy, float* dw, int B, int Ci, int H, int W,
+                      int Co, int KS, int up2, int accumulate, void* ws, size_t ws_bytes, void* stream);
+/* db[C] (+)= sum_{b,hw} dy[b][c][hw]  (bias gradients: models.py:290 predict, :233/:270 Linear) */
+int itcv_bias_grad(const float* dy, float* db, int B, int C, int HW, int accumulate, void* stream);
+
+/* ---- BatchNorm2d (+ LeakyReLU, + AvgPool2d(2)) ---------------------------------------
+ * Replaces nn.BatchNorm2d(eps) -> nn.LeakyReLU(0.2) [-> nn.AvgPool2d(2)]: models.py:37-38,48-49,
+ * 214-216,225.  Train-mode statistics are computed in fp64 from per-channel (sum, sum of
+ * squares); the moments are exposed so that a data-parallel caller can all-reduce them
+ * (Sync-BN) between _moments and _finalize. */
+size_t itcv_bn_workspace(int B, int C, int HW);
+/* sums[0..C) = sum x, sums[C..2C) = sum x^2 over (b,hw); deterministic two-stage reduction */
+int itcv_bn_moments(const float* x, double* sums, int B, int C, int HW, void* ws, size_t ws_bytes,
+                    void* stream);
+/* mean/rstd from the moments of `count` samples; updates running_mean/var (momentum, unbiased
+ * variance) and num_batches_tracked when those pointers are non-NULL. */
+int itcv_bn_finalize(const double* sums, double count, float eps, float momentum, float* running_mean,
+                     float* running_var, int64_t* num_batches_tracked, float* mean, float* rstd, int C,
+                     void* stream);
+/* eval mode: mean = running_mean, rstd = 1/sqrt(running_var + eps) */
+int itcv_bn_eval_stats(const float* running_mean, const float* running_var, float eps, float* mean,
+                       float* rstd, int C, void* stream);
+/* y = pool(lrelu(gamma*(x-mean)*rstd + beta, slope)); slope = 1 disables the activation; pool in
+ * {0: none (y [B][C][H][W]), 1: 2x2 average (y [B][C][H/2][W/2])}.  If `skip` is non-NULL it is
+ * added before the activation (ResidualBlock, models.py:113-114). */
+int itcv_bn_act_fwd(const float* x, const float* mean, const float* rstd, const float* gamma,
+                    const float* beta, const float* skip, float* y, int B, int C, int H, int W,
+                    float slope, int pool, void* stream);
+/* backward, stage 1: dsums[0..C) = sum g, dsums[C..2C) = sum g*xhat where
+ * g = unpool(dy) * lrelu'(bn_out (+skip)); `up2`!=0 means dy is the gradient of the x2-upsampled
+ * output (dy [B][C][2H][2W], summed 2x2 on the fly: adjoint of models.py:284-286). */
+int itcv_bn_act_bwd_reduce(const float* x, const float* dy, const float* mean, const float* rstd,
+                           const float* gamma, const float* beta, const float* skip, double* dsums,
+                           int B, int C, int H, int W, float slope, int pool, int up2, void* ws,
+                           size_t ws_bytes, void* stream);
+/* backward, stage 2: dx = gamma*rstd*(g - dsums[c]/count - xhat*dsums[C+c]/count);
+ * dgamma (+)= local_dsums[C+c], dbeta (+)= local_dsums[c] when non-NULL (local_dsums = the rank's
+ * own sums; dsums may have been all-reduced for Sync-BN); dskip = g when non-NULL. */
+int itcv_bn_act_bwd_apply(const float* x, const float* dy, const float* mean, const float* rstd,
+                          const float* gamma, const float* beta, const float* skip, const double* dsums,
+                          const double* local_dsums, double count, float* dx, float* dskip,
+                          float* dgamma, float* dbeta, int accumulate, int B, int C, int H, int W,
+                          float slope, int pool, int up2, void* stream);
+
+/* ---- pointwise / resampling ----------------------------------------------------------- */
+int itcv_lrelu_fwd(const float* x, float* y, size_t n, float slope, void* stream);     /* models.py:271 */
+int itcv_lrelu_bwd(const float* x, const float* dy, float* dx, size_t n, float slope, void* stream);
+int itcv_sigmoid_fwd(const float* x, float* y, size_t n, void* stream);                /* models.py:291 */
+int itcv_sigmoid_bwd(const float* y, const float* dy, float* dx, size_t n, void* stream);
+int itcv_avgpool2_fwd(const float* x, float* y, int BC, int H, int W, void* stream);   /* models.py:216,225 */
+int itcv_avgpool2_bwd(const float* dy, float* dx, int BC, int H, int W, void* stream);
+int itcv_upsample2_fwd(const float* x, float* y, int BC, int H, int W, void* stream);  /* models.py:284 */
+int itcv_upsample2_bwd(const float* dy, float* dx, int BC, int H, int W, void* stream);
+int itcv_add(const float* a, const float* b, float* out, size_t n, void* stream);      /* models.py:114,182 */
+
+/* ---- latent math (ops.py) ------------------------------------------------------------- */
+/* ops.py:166-185  z = mu + eps*exp(0.5*logvar) */
+int itcv_reparam_fwd(const float* mu, const float* logvar, const float* eps, float* z, size_t n,
+                     void* stream);
+int itcv_reparam_bwd(const float* dz, const float* logvar, const float* eps, float* dmu, float* dlogvar,
+                     size_t n, void* stream);
+/* ops.py:161-163  kl[j] = -0.5 * sum_l (1 + lv - exp(lv) - mu^2) */
+int itcv_kl_rows_fwd(const float* logvar, const float* mu, float* kl, int B, int D, void* stream);
+int itcv_kl_rows_bwd(const float* g, const float* logvar, const float* mu, float* dlogvar, float* dmu,
+                     int B, int D, void* stream);
+
+/* ops.py:15-29,32-49,52-115: pairwise Gaussian log-density + minibatch stratified / weighted
+ * sampling, fused; the [B,B,D] tensor is never materialised.
+ *   rows j: the caller's local samples z[Bl][D] (global row index = row_offset + j)
+ *   cols i: all samples' means mu_all[Bt][D] (all-gathered in data-parallel runs)
+ *   logvar: [Bl][D] (rows) with ITCV_TC_VAR_FROM_ROW, else [Bt][D] (columns)
+ *   flags: ITCV_TC_*   variance source, density flavour and sampler
+ * Outputs: prodm[Bl] = sum_l logsumexp_i(logW[j,i] + lp[j,i,l]),
+ *          logqz[Bl] = logsumexp_i(logW[j,i] + sum_l lp[j,i,l]),
+ *          lse[Bl][D]  (saved per-dimension logsumexp, needed by the backward). */
+#define ITCV_TC_VAR_FROM_ROW 0x1 /* ops.py:81 logvar.unsqueeze(1): variance of sample row j (live path) */
+#define ITCV_TC_EPS_DENSITY 0x2  /* ops.py:15-21 density (var clamp 1e-4, straight-through) else ops.py:24-29 */
+#define ITCV_TC_WEIGHTED 0x4     /* ops.py:92-101 MWS; default ops.py:104-115 MSS */
+#define ITCV_TC_LIVE (ITCV_TC_VAR_FROM_ROW | ITCV_TC_EPS_DENSITY)
+int itcv_tc_fwd(const float* z, const float* mu_all, const float* logvar, float* prodm, float* logqz,
+                float* lse, int Bl, int Bt, int row_offset, int D, int64_t dataset_size, int flags,
+                void* stream);
+/* gradient of sum_j g[j] * (logqz[j] - prodm[j]) for the live path (flags == ITCV_TC_LIVE):
+ * dz[Bl][D], dlogvar[Bl][D] (rows) and dmu_all[Bt][D] (columns; partial over this rank's rows). */
+size_t itcv_tc_bwd_workspace(int Bl, int Bt);
+int itcv_tc_bwd(const float* g, const float* z, const float* mu_all, const float* logvar,
+                const float* logqz, const float* lse, float* dz, float* dmu_all, float* dlogvar, int Bl,
+                int Bt, int row_offset, int D, int64_t dataset_size, int flags, void* ws, size_t ws_bytes,
+                void* stream);
+/* solvers/tc.py:104-121: per-sample log q(z|x) (ops.py:24-29 density, own mu/logvar) and log p(z) */
+int itcv_diag_logdensity_rows(const float* z, const float* mu, const float* logvar, float* logq_cx,
+                              float* logpz, int B, int D, void* stream);
+
+/* ---- reconstruction loss (ops.py:188-236) --------------------------------------------- */
+#define ITCV_LOSS_MSE 0
+#define ITCV_LOSS_L1 1
+#define ITCV_LOSS_BCE 2
+/* rows[b] = sum_p err(recon[b][p], x[b][p]) */
+int itcv_recon_rows_fwd(const float* x, const float* recon, float* rows, int B, size_t P, int loss_type,
+                        void* ws, size_t ws_bytes, void* stream);
+size_t itcv_recon_workspace(int B, size_t P);
+/* drecon[b][p] = g[b] * d err / d recon */
+int itcv_recon_rows_bwd(const float* x, const float* recon, const float* g, float* drecon, int B, size_t P,
+                        int loss_type, void* stream);
+
+/* ---- optimiser (train.py:141-144, solvers/intro.py:109-116,153-160) --------------------- */
+/* out[0] = sum x^2 (fp64, deterministic) */
+size_t itcv_sumsq_workspace(size_t n);
+int itcv_sumsq(const float* x, size_t n, double* out, void* ws, size_t ws_bytes, void* stream);
+/* torch.nn.utils.clip_grad_norm_: total = sqrt(sum_k sumsq[k]); coef = min(1, clip/(total+1e-6));
+ * writes norm_out[0] = total, coef_out[0] = coef (device scalars, no host sync) */
+int itcv_clip_coef(const double* sumsq, int nparts, double clip, float* norm_out, float* coef_out,
+                   void* stream);
+int itcv_scale_by_dev(float* x, size_t n, const float* coef_dev, void* stream);
+/* torch.optim.Adam defaults (no amsgrad / weight decay), one flat launch; step is 1-based */
+int itcv_adam_step(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1,
+                   float beta2, float eps, int step, void* stream);
+int itcv_fill(float* x, size_t n, float value, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ITCV_HIP_H */

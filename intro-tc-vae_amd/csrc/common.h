@@ -1,0 +1,77 @@
+// Shared helpers for libitcv_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/itcv_hip.h"
+
+namespace itcv {
+
+extern thread_local char g_err[512];
+
+inline int fail(const char* fmt, const char* a = "", long long b = 0, long long c = 0) {
+  snprintf(g_err, sizeof(g_err), fmt, a, b, c);
+  return 1;
+}
+
+#define ITCV_CHECK_LAUNCH(name)                                                        \
+  do {                                                                                 \
+    hipError_t e_ = hipGetLastError();                                                 \
+    if (e_ != hipSuccess) return itcv::fail("%s: launch failed: %lld", name, (long long)e_); \
+  } while (0)
+
+#define ITCV_REQUIRE(cond, name)                                              \
+  do {                                                                        \
+    if (!(cond)) return itcv::fail("%s: requirement failed: " #cond, name);   \
+  } while (0)
+
+inline hipStream_t S(void* s) { return reinterpret_cast<hipStream_t>(s); }
+
+__host__ __device__ inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+inline size_t cdivz(size_t a, size_t b) { return (a + b - 1) / b; }
+inline size_t align_up(size_t a, size_t b) { return cdivz(a, b) * b; }
+
+constexpr int kWave = 64;
+
+// ---- wave / block reductions (wave = 64 lanes) -------------------------------------------
+template <typename T>
+__device__ __forceinline__ T wave_sum(T v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+template <typename T>
+__device__ __forceinline__ T wave_max(T v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    T u = __shfl_xor(v, o, 64);
+    v = u > v ? u : v;
+  }
+  return v;
+}
+// block-wide sum; result valid in every thread.  `scratch` holds >= blockDim/64 elements.
+template <typename T>
+__device__ __forceinline__ T block_sum(T v, T* scratch) {
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  v = wave_sum(v);
+  __syncthreads();
+  if (lane == 0) scratch[wid] = v;
+  __syncthreads();
+  T r = 0;
+  for (int i = 0; i < nw; ++i) r += scratch[i];  // fixed order: deterministic
+  return r;
+}
+
+// 128-bit buffer resource for raw buffer loads with hardware bounds checking: an offset
+// >= num_bytes returns 0, which is how padding / tile tails are zero-filled without branches.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, uint32_t num_bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, num_bytes, 0x00020000);
+}
+__device__ __forceinline__ float buf_load(__amdgpu_buffer_rsrc_t r, uint32_t byte_off) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, byte_off, 0, 0));
+}
+constexpr uint32_t kOOB = 0xFFFFFFFFu;
+
+}  // namespace itcv

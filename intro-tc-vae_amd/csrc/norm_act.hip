@@ -1,0 +1,449 @@
+// BatchNorm2d(train) + LeakyReLU (+ AvgPool2d(2) / nearest-Upsample(2) adjoints), and the
+// pointwise / resampling kernels of the encoder/decoder stacks.  All HBM-bound: one coalesced
+// pass per tensor, fp64 channel statistics with a deterministic two-stage reduction.
+// Replaces /root/reference/models.py:37-38,48-49,214-216,225,271,284-286,291.
+#include "common.h"
+
+namespace itcv {
+
+constexpr int kRedThreads = 256;
+
+// ------------------------------------------------------------------ channel moments (fp64)
+// grid (C, splits): block (c, s) reduces its slice of channel c's B*HW values
+__global__ __launch_bounds__(kRedThreads) void bn_moments_partial(const float* __restrict__ x,
+                                                                  double* __restrict__ part, int B, int C, int HW,
+                                                                  int splits) {
+  __shared__ double scratch[kRedThreads / 64];
+  const int c = blockIdx.x, s = blockIdx.y;
+  const size_t total = (size_t)B * HW;
+  const size_t chunk = ((total + splits - 1) / splits + 3) & ~(size_t)3;  // multiple of 4: float4 stays aligned
+  const size_t beg = (size_t)s * chunk, end = beg + chunk < total ? beg + chunk : total;
+  double s1 = 0.0, s2 = 0.0;
+  if ((HW & 3) == 0) {
+    for (size_t i = beg + (size_t)threadIdx.x * 4; i < end; i += (size_t)kRedThreads * 4) {
+      const size_t b = i / HW, hw = i - b * HW;
+      const float4 v = *reinterpret_cast<const float4*>(x + (b * C + c) * HW + hw);
+      s1 += (double)v.x + (double)v.y + (double)v.z + (double)v.w;
+      s2 += (double)v.x * v.x + (double)v.y * v.y + (double)v.z * v.z + (double)v.w * v.w;
+    }
+  } else {
+    for (size_t i = beg + threadIdx.x; i < end; i += kRedThreads) {
+      const size_t b = i / HW, hw = i - b * HW;
+      const float v = x[(b * C + c) * HW + hw];
+      s1 += (double)v;
+      s2 += (double)v * v;
+    }
+  }
+  s1 = block_sum(s1, scratch);
+  s2 = block_sum(s2, scratch);
+  if (threadIdx.x == 0) {
+    part[((size_t)s * 2 + 0) * C + c] = s1;
+    part[((size_t)s * 2 + 1) * C + c] = s2;
+  }
+}
+
+// sums[k][c] = sum_s part[s][k][c]   (k in {0,1}), fixed order
+__global__ void combine_partials(const double* __restrict__ part, double* __restrict__ sums, int C2, int splits) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= C2) return;
+  double s = 0.0;
+  for (int k = 0; k < splits; ++k) s += part[(size_t)k * C2 + i];
+  sums[i] = s;
+}
+
+__global__ void bn_finalize_kernel(const double* __restrict__ sums, double count, float eps, float momentum,
+                                   float* running_mean, float* running_var, int64_t* nbt, float* mean, float* rstd,
+                                   int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c == 0 && nbt) nbt[0] += 1;
+  if (c >= C) return;
+  const double m = sums[c] / count;
+  double var = sums[C + c] / count - m * m;
+  if (var < 0.0) var = 0.0;
+  mean[c] = (float)m;
+  rstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+  if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)m;
+  if (running_var) {
+    const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+    running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+  }
+}
+
+__global__ void bn_eval_stats_kernel(const float* rm, const float* rv, float eps, float* mean, float* rstd, int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  mean[c] = rm[c];
+  rstd[c] = 1.f / sqrtf(rv[c] + eps);
+}
+
+__device__ __forceinline__ float lrelu(float v, float slope) { return v > 0.f ? v : v * slope; }
+
+// ------------------------------------------------------------------ forward apply
+// y = pool(lrelu(gamma*(x-mean)*rstd + beta (+skip)))
+template <int POOL>
+__global__ void bn_act_fwd_kernel(const float* __restrict__ x, const float* __restrict__ mean,
+                                  const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                  const float* __restrict__ beta, const float* __restrict__ skip,
+                                  float* __restrict__ y, int C, int H, int W, size_t nout, float slope) {
+  const int HW = H * W;
+  if (POOL == 0) {
+    // 4 consecutive pixels per thread (HW % 4 == 0 is checked on the host)
+    for (size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < nout;
+         i += (size_t)gridDim.x * blockDim.x * 4) {
+      const int c = (int)((i / HW) % C);
+      const float sc = gamma[c] * rstd[c], sh = beta[c] - mean[c] * sc;
+      float4 v = *reinterpret_cast<const float4*>(x + i);
+      v.x = v.x * sc + sh, v.y = v.y * sc + sh, v.z = v.z * sc + sh, v.w = v.w * sc + sh;
+      if (skip) {
+        const float4 k = *reinterpret_cast<const float4*>(skip + i);
+        v.x += k.x, v.y += k.y, v.z += k.z, v.w += k.w;
+      }
+      v.x = lrelu(v.x, slope), v.y = lrelu(v.y, slope), v.z = lrelu(v.z, slope), v.w = lrelu(v.w, slope);
+      *reinterpret_cast<float4*>(y + i) = v;
+    }
+  } else {
+    const int Ho = H / 2, Wo = W / 2, HWo = Ho * Wo;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nout; i += (size_t)gridDim.x * blockDim.x) {
+      const size_t bc = i / HWo;
+      const int r = (int)(i - bc * HWo), ho = r / Wo, wo = r - ho * Wo;
+      const int c = (int)(bc % C);
+      const float sc = gamma[c] * rstd[c], sh = beta[c] - mean[c] * sc;
+      const size_t src = bc * HW + (size_t)(2 * ho) * W + 2 * wo;
+      const float2 a = *reinterpret_cast<const float2*>(x + src);
+      const float2 b = *reinterpret_cast<const float2*>(x + src + W);
+      float v0 = a.x * sc + sh, v1 = a.y * sc + sh, v2 = b.x * sc + sh, v3 = b.y * sc + sh;
+      if (skip) {
+        const float2 ka = *reinterpret_cast<const float2*>(skip + src);
+        const float2 kb = *reinterpret_cast<const float2*>(skip + src + W);
+        v0 += ka.x, v1 += ka.y, v2 += kb.x, v3 += kb.y;
+      }
+      y[i] = 0.25f * (lrelu(v0, slope) + lrelu(v1, slope) + lrelu(v2, slope) + lrelu(v3, slope));
+    }
+  }
+}
+
+// ------------------------------------------------------------------ backward
+// upstream gradient of the pre-activation u = bn(x) (+skip) at pixel (bc, h, w):
+//   MODE 0: dy same shape;  MODE 1: dy is the gradient of the 2x2-average-pooled output;
+//   MODE 2: dy is the gradient of the nearest x2 upsampled output (sum of its 4 children).
+template <int MODE>
+__device__ __forceinline__ float upstream(const float* __restrict__ dy, size_t bc, int h, int w, int H, int W) {
+  if (MODE == 0) return dy[bc * H * W + (size_t)h * W + w];
+  if (MODE == 1) return 0.25f * dy[bc * (H / 2) * (W / 2) + (size_t)(h >> 1) * (W / 2) + (w >> 1)];
+  const size_t base = bc * (size_t)(4 * H * W) + (size_t)(2 * h) * (2 * W) + 2 * w;
+  const float2 a = *reinterpret_cast<const float2*>(dy + base);
+  const float2 b = *reinterpret_cast<const float2*>(dy + base + 2 * W);
+  return (a.x + a.y) + (b.x + b.y);
+}
+
+template <int MODE>
+__global__ __launch_bounds__(kRedThreads) void bn_bwd_partial(const float* __restrict__ x,
+                                                              const float* __restrict__ dy,
+                                                              const float* __restrict__ mean,
+                                                              const float* __restrict__ rstd,
+                                                              const float* __restrict__ gamma,
+                                                              const float* __restrict__ beta,
+                                                              const float* __restrict__ skip,
+                                                              double* __restrict__ part, int B, int C, int H, int W,
+                                                              float slope, int splits) {
+  __shared__ double scratch[kRedThreads / 64];
+  const int c = blockIdx.x, s = blockIdx.y, HW = H * W;
+  const size_t total = (size_t)B * HW;
+  const size_t chunk = (total + splits - 1) / splits;
+  const size_t beg = (size_t)s * chunk, end = beg + chunk < total ? beg + chunk : total;
+  const float mu = mean[c], rs = rstd[c], ga = gamma[c], be = beta[c];
+  double s1 = 0.0, s2 = 0.0;
+  for (size_t i = beg + threadIdx.x; i < end; i += kRedThreads) {
+    const size_t b = i / HW;
+    const int hw = (int)(i - b * HW), h = hw / W, w = hw - h * W;
+    const size_t bc = b * C + c;
+    const float xh = (x[bc * HW + hw] - mu) * rs;
+    float u = xh * ga + be;
+    if (skip) u += skip[bc * HW + hw];
+    float g = upstream<MODE>(dy, bc, h, w, H, W);
+    if (!(u > 0.f)) g *= slope;
+    s1 += (double)g;
+    s2 += (double)g * (double)xh;
+  }
+  s1 = block_sum(s1, scratch);
+  s2 = block_sum(s2, scratch);
+  if (threadIdx.x == 0) {
+    part[((size_t)s * 2 + 0) * C + c] = s1;
+    part[((size_t)s * 2 + 1) * C + c] = s2;
+  }
+}
+
+template <int MODE>
+__global__ void bn_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                    const float* __restrict__ mean, const float* __restrict__ rstd,
+                                    const float* __restrict__ gamma, const float* __restrict__ beta,
+                                    const float* __restrict__ skip, const double* __restrict__ dsums, double count,
+                                    float* __restrict__ dx, float* __restrict__ dskip, int C, int H, int W,
+                                    size_t n, float slope) {
+  const int HW = H * W;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t bc = i / HW;
+    const int hw = (int)(i - bc * HW), h = hw / W, w = hw - h * W;
+    const int c = (int)(bc % C);
+    const float mu = mean[c], rs = rstd[c], ga = gamma[c];
+    const float xh = (x[i] - mu) * rs;
+    float u = xh * ga + beta[c];
+    if (skip) u += skip[i];
+    float g = upstream<MODE>(dy, bc, h, w, H, W);
+    if (!(u > 0.f)) g *= slope;
+    const float m1 = (float)(dsums[c] / count), m2 = (float)(dsums[C + c] / count);
+    dx[i] = ga * rs * (g - m1 - xh * m2);
+    if (dskip) dskip[i] = g;
+  }
+}
+
+__global__ void bn_param_grad_kernel(const double* __restrict__ local, float* dgamma, float* dbeta, int C,
+                                     int accumulate) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  if (dbeta) dbeta[c] = (accumulate ? dbeta[c] : 0.f) + (float)local[c];
+  if (dgamma) dgamma[c] = (accumulate ? dgamma[c] : 0.f) + (float)local[C + c];
+}
+
+// ------------------------------------------------------------------ pointwise / resampling
+__global__ void lrelu_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, size_t n, float slope) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    y[i] = lrelu(x[i], slope);
+}
+__global__ void lrelu_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dx,
+                                 size_t n, float slope) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    dx[i] = x[i] > 0.f ? dy[i] : dy[i] * slope;
+}
+__global__ void sigmoid_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    y[i] = 1.f / (1.f + expf(-x[i]));
+}
+__global__ void sigmoid_bwd_kernel(const float* __restrict__ y, const float* __restrict__ dy,
+                                   float* __restrict__ dx, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const float s = y[i];
+    dx[i] = dy[i] * (1.f - s) * s;
+  }
+}
+__global__ void add_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ o,
+                           size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    o[i] = a[i] + b[i];
+}
+// y[bc][ho][wo] = mean of the 2x2 window
+__global__ void avgpool2_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int H, int W, size_t nout) {
+  const int Ho = H / 2, Wo = W / 2;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nout; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t bc = i / ((size_t)Ho * Wo);
+    const int r = (int)(i - bc * Ho * Wo), ho = r / Wo, wo = r - ho * Wo;
+    const size_t src = bc * H * W + (size_t)(2 * ho) * W + 2 * wo;
+    const float2 a = *reinterpret_cast<const float2*>(x + src);
+    const float2 b = *reinterpret_cast<const float2*>(x + src + W);
+    y[i] = 0.25f * ((a.x + a.y) + (b.x + b.y));
+  }
+}
+// dx[bc][h][w] = 0.25 * dy[bc][h/2][w/2]       (n = elements of dx)
+__global__ void avgpool2_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, int H, int W, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t bc = i / ((size_t)H * W);
+    const int r = (int)(i - bc * H * W), h = r / W, w = r - h * W;
+    dx[i] = 0.25f * dy[bc * (H / 2) * (W / 2) + (size_t)(h >> 1) * (W / 2) + (w >> 1)];
+  }
+}
+// y[bc][2h+a][2w+b] = x[bc][h][w]             (n = elements of y, H/W = input dims)
+__global__ void upsample2_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int H, int W, size_t n) {
+  const int Ho = 2 * H, Wo = 2 * W;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t bc = i / ((size_t)Ho * Wo);
+    const int r = (int)(i - bc * Ho * Wo), h = r / Wo, w = r - h * Wo;
+    y[i] = x[bc * H * W + (size_t)(h >> 1) * W + (w >> 1)];
+  }
+}
+// dx[bc][h][w] = sum of the 4 children        (n = elements of dx, H/W = dims of dx)
+__global__ void upsample2_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, int H, int W, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t bc = i / ((size_t)H * W);
+    const int r = (int)(i - bc * H * W), h = r / W, w = r - h * W;
+    dx[i] = upstream<2>(dy, bc, h, w, H, W);
+  }
+}
+
+static inline int grid_for(size_t n, int per_thread = 1) {
+  size_t b = cdivz(cdivz(n, per_thread), 256);
+  if (b > 256 * 8) b = 256 * 8;  // grid-stride the rest (>= 8 blocks per CU resident)
+  return b < 1 ? 1 : (int)b;
+}
+
+static inline int bn_splits(int B, int C, int HW) {
+  const size_t total = (size_t)B * HW;
+  int s = cdiv(2048, C);
+  const size_t maxs = cdivz(total, 1024);
+  if ((size_t)s > maxs) s = (int)maxs;
+  if (s < 1) s = 1;
+  // keep every slice a multiple of 4 elements so the float4 path stays aligned
+  return s;
+}
+
+}  // namespace itcv
+
+using namespace itcv;
+
+extern "C" {
+
+size_t itcv_bn_workspace(int B, int C, int HW) {
+  if (B <= 0 || C <= 0 || HW <= 0) return 0;
+  return (size_t)bn_splits(B, C, HW) * 2 * C * sizeof(double);
+}
+
+int itcv_bn_moments(const float* x, double* sums, int B, int C, int HW, void* ws, size_t ws_bytes, void* stream) {
+  ITCV_REQUIRE(x && sums && B > 0 && C > 0 && HW > 0, "itcv_bn_moments");
+  const int splits = bn_splits(B, C, HW);
+  ITCV_REQUIRE(ws && ws_bytes >= (size_t)splits * 2 * C * sizeof(double), "itcv_bn_moments(workspace)");
+  double* part = static_cast<double*>(ws);
+  hipLaunchKernelGGL(bn_moments_partial, dim3(C, splits), dim3(kRedThreads), 0, S(stream), x, part, B, C, HW, splits);
+  ITCV_CHECK_LAUNCH("itcv_bn_moments");
+  hipLaunchKernelGGL(combine_partials, dim3(cdiv(2 * C, 256)), dim3(256), 0, S(stream), part, sums, 2 * C, splits);
+  ITCV_CHECK_LAUNCH("itcv_bn_moments(combine)");
+  return 0;
+}
+
+int itcv_bn_finalize(const double* sums, double count, float eps, float momentum, float* running_mean,
+                     float* running_var, int64_t* num_batches_tracked, float* mean, float* rstd, int C,
+                     void* stream) {
+  ITCV_REQUIRE(sums && mean && rstd && C > 0 && count > 0, "itcv_bn_finalize");
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 256)), dim3(256), 0, S(stream), sums, count, eps, momentum,
+                     running_mean, running_var, num_batches_tracked, mean, rstd, C);
+  ITCV_CHECK_LAUNCH("itcv_bn_finalize");
+  return 0;
+}
+
+int itcv_bn_eval_stats(const float* running_mean, const float* running_var, float eps, float* mean, float* rstd,
+                       int C, void* stream) {
+  ITCV_REQUIRE(running_mean && running_var && mean && rstd && C > 0, "itcv_bn_eval_stats");
+  hipLaunchKernelGGL(bn_eval_stats_kernel, dim3(cdiv(C, 256)), dim3(256), 0, S(stream), running_mean, running_var,
+                     eps, mean, rstd, C);
+  ITCV_CHECK_LAUNCH("itcv_bn_eval_stats");
+  return 0;
+}
+
+int itcv_bn_act_fwd(const float* x, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                    const float* skip, float* y, int B, int C, int H, int W, float slope, int pool, void* stream) {
+  ITCV_REQUIRE(x && mean && rstd && gamma && beta && y && B > 0 && C > 0 && H > 0 && W > 0, "itcv_bn_act_fwd");
+  if (pool) {
+    ITCV_REQUIRE(H % 2 == 0 && W % 2 == 0, "itcv_bn_act_fwd(pool)");
+    const size_t nout = (size_t)B * C * (H / 2) * (W / 2);
+    hipLaunchKernelGGL(bn_act_fwd_kernel<1>, dim3(grid_for(nout)), dim3(256), 0, S(stream), x, mean, rstd, gamma,
+                       beta, skip, y, C, H, W, nout, slope);
+  } else {
+    ITCV_REQUIRE((H * W) % 4 == 0, "itcv_bn_act_fwd(H*W % 4)");
+    const size_t nout = (size_t)B * C * H * W;
+    hipLaunchKernelGGL(bn_act_fwd_kernel<0>, dim3(grid_for(nout, 4)), dim3(256), 0, S(stream), x, mean, rstd, gamma,
+                       beta, skip, y, C, H, W, nout, slope);
+  }
+  ITCV_CHECK_LAUNCH("itcv_bn_act_fwd");
+  return 0;
+}
+
+int itcv_bn_act_bwd_reduce(const float* x, const float* dy, const float* mean, const float* rstd, const float* gamma,
+                           const float* beta, const float* skip, double* dsums, int B, int C, int H, int W,
+                           float slope, int pool, int up2, void* ws, size_t ws_bytes, void* stream) {
+  ITCV_REQUIRE(x && dy && mean && rstd && gamma && beta && dsums && B > 0 && C > 0, "itcv_bn_act_bwd_reduce");
+  ITCV_REQUIRE(!(pool && up2), "itcv_bn_act_bwd_reduce(pool and up2 are exclusive)");
+  if (pool) ITCV_REQUIRE(H % 2 == 0 && W % 2 == 0, "itcv_bn_act_bwd_reduce(pool)");
+  const int splits = bn_splits(B, C, H * W);
+  ITCV_REQUIRE(ws && ws_bytes >= (size_t)splits * 2 * C * sizeof(double), "itcv_bn_act_bwd_reduce(workspace)");
+  double* part = static_cast<double*>(ws);
+  dim3 grid(C, splits);
+  if (pool)
+    hipLaunchKernelGGL(bn_bwd_partial<1>, grid, dim3(kRedThreads), 0, S(stream), x, dy, mean, rstd, gamma, beta, skip,
+                       part, B, C, H, W, slope, splits);
+  else if (up2)
+    hipLaunchKernelGGL(bn_bwd_partial<2>, grid, dim3(kRedThreads), 0, S(stream), x, dy, mean, rstd, gamma, beta, skip,
+                       part, B, C, H, W, slope, splits);
+  else
+    hipLaunchKernelGGL(bn_bwd_partial<0>, grid, dim3(kRedThreads), 0, S(stream), x, dy, mean, rstd, gamma, beta, skip,
+                       part, B, C, H, W, slope, splits);
+  ITCV_CHECK_LAUNCH("itcv_bn_act_bwd_reduce");
+  hipLaunchKernelGGL(combine_partials, dim3(cdiv(2 * C, 256)), dim3(256), 0, S(stream), part, dsums, 2 * C, splits);
+  ITCV_CHECK_LAUNCH("itcv_bn_act_bwd_reduce(combine)");
+  return 0;
+}
+
+int itcv_bn_act_bwd_apply(const float* x, const float* dy, const float* mean, const float* rstd, const float* gamma,
+                          const float* beta, const float* skip, const double* dsums, const double* local_dsums,
+                          double count, float* dx, float* dskip, float* dgamma, float* dbeta, int accumulate, int B,
+                          int C, int H, int W, float slope, int pool, int up2, void* stream) {
+  ITCV_REQUIRE(x && dy && mean && rstd && gamma && beta && dsums && dx && B > 0 && C > 0 && count > 0,
+               "itcv_bn_act_bwd_apply");
+  ITCV_REQUIRE(!(pool && up2), "itcv_bn_act_bwd_apply(pool and up2 are exclusive)");
+  const size_t n = (size_t)B * C * H * W;
+  dim3 grid(grid_for(n));
+  if (pool)
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<1>, grid, dim3(256), 0, S(stream), x, dy, mean, rstd, gamma, beta, skip,
+                       dsums, count, dx, dskip, C, H, W, n, slope);
+  else if (up2)
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<2>, grid, dim3(256), 0, S(stream), x, dy, mean, rstd, gamma, beta, skip,
+                       dsums, count, dx, dskip, C, H, W, n, slope);
+  else
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<0>, grid, dim3(256), 0, S(stream), x, dy, mean, rstd, gamma, beta, skip,
+                       dsums, count, dx, dskip, C, H, W, n, slope);
+  ITCV_CHECK_LAUNCH("itcv_bn_act_bwd_apply");
+  if (dgamma || dbeta) {
+    hipLaunchKernelGGL(bn_param_grad_kernel, dim3(cdiv(C, 256)), dim3(256), 0, S(stream),
+                       local_dsums ? local_dsums : dsums, dgamma, dbeta, C, accumulate);
+    ITCV_CHECK_LAUNCH("itcv_bn_act_bwd_apply(param grads)");
+  }
+  return 0;
+}
+
+#define ITCV_POINTWISE(NAME, KERNEL, N, ...)                                                        \
+  do {                                                                                              \
+    if ((N) == 0) return 0;                                                                         \
+    hipLaunchKernelGGL(KERNEL, dim3(grid_for(N)), dim3(256), 0, S(stream), __VA_ARGS__);            \
+    ITCV_CHECK_LAUNCH(NAME);                                                                        \
+    return 0;                                                                                       \
+  } while (0)
+
+int itcv_lrelu_fwd(const float* x, float* y, size_t n, float slope, void* stream) {
+  ITCV_REQUIRE(x && y, "itcv_lrelu_fwd");
+  ITCV_POINTWISE("itcv_lrelu_fwd", lrelu_fwd_kernel, n, x, y, n, slope);
+}
+int itcv_lrelu_bwd(const float* x, const float* dy, float* dx, size_t n, float slope, void* stream) {
+  ITCV_REQUIRE(x && dy && dx, "itcv_lrelu_bwd");
+  ITCV_POINTWISE("itcv_lrelu_bwd", lrelu_bwd_kernel, n, x, dy, dx, n, slope);
+}
+int itcv_sigmoid_fwd(const float* x, float* y, size_t n, void* stream) {
+  ITCV_REQUIRE(x && y, "itcv_sigmoid_fwd");
+  ITCV_POINTWISE("itcv_sigmoid_fwd", sigmoid_fwd_kernel, n, x, y, n);
+}
+int itcv_sigmoid_bwd(const float* y, const float* dy, float* dx, size_t n, void* stream) {
+  ITCV_REQUIRE(y && dy && dx, "itcv_sigmoid_bwd");
+  ITCV_POINTWISE("itcv_sigmoid_bwd", sigmoid_bwd_kernel, n, y, dy, dx, n);
+}
+int itcv_add(const float* a, const float* b, float* out, size_t n, void* stream) {
+  ITCV_REQUIRE(a && b && out, "itcv_add");
+  ITCV_POINTWISE("itcv_add", add_kernel, n, a, b, out, n);
+}
+int itcv_avgpool2_fwd(const float* x, float* y, int BC, int H, int W, void* stream) {
+  ITCV_REQUIRE(x && y && BC > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0, "itcv_avgpool2_fwd");
+  const size_t n = (size_t)BC * (H / 2) * (W / 2);
+  ITCV_POINTWISE("itcv_avgpool2_fwd", avgpool2_fwd_kernel, n, x, y, H, W, n);
+}
+int itcv_avgpool2_bwd(const float* dy, float* dx, int BC, int H, int W, void* stream) {
+  ITCV_REQUIRE(dy && dx && BC > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0, "itcv_avgpool2_bwd");
+  const size_t n = (size_t)BC * H * W;
+  ITCV_POINTWISE("itcv_avgpool2_bwd", avgpool2_bwd_kernel, n, dy, dx, H, W, n);
+}
+int itcv_upsample2_fwd(const float* x, float* y, int BC, int H, int W, void* stream) {
+  ITCV_REQUIRE(x && y && BC > 0 && H > 0 && W > 0, "itcv_upsample2_fwd");
+  const size_t n = (size_t)BC * H * W * 4;
+  ITCV_POINTWISE("itcv_upsample2_fwd", upsample2_fwd_kernel, n, x, y, H, W, n);
+}
+int itcv_upsample2_bwd(const float* dy, float* dx, int BC, int H, int W, void* stream) {
+  ITCV_REQUIRE(dy && dx && BC > 0 && H > 0 && W > 0, "itcv_upsample2_bwd");
+  const size_t n = (size_t)BC * H * W;
+  ITCV_POINTWISE("itcv_upsample2_bwd", upsample2_bwd_kernel, n, dy, dx, H, W, n);
+}
+
+}  // extern "C"

@@ -1,0 +1,407 @@
+"""torch.autograd.Function wrappers around the HIP kernels of libitcv_hip.so.
+
+Each Function forwards device pointers to one or a few C-ABI entry points (hipvae.abi) and
+keeps only what its backward needs.  PyTorch provides memory, the stream and the autograd
+tape; all arithmetic on activations, gradients and statistics happens in the HIP kernels.
+The optional ``group`` arguments are torch.distributed process groups: they turn BatchNorm
+into Sync-BN (all-reduce of the fp64 channel moments over RCCL) for data-parallel parity
+with the full-batch reference.
+"""
+import torch
+import torch.distributed as dist
+from torch.autograd import Function
+from torch.autograd.function import once_differentiable
+
+from . import abi
+from .abi import call, lib, ptr, stream
+
+F32 = torch.float32
+
+
+def _ws(nbytes, device):
+    return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)
+
+
+def _f32c(t):
+    if t.dtype != F32:
+        raise abi.HipExtensionError(f"HIP path is fp32 only (got {t.dtype})")
+    return t if t.is_contiguous() else t.contiguous()
+
+
+# ------------------------------------------------------------------ convolution / linear
+def pack_weight(w4, for_dgrad):
+    """w4 [Co,Ci,KS,KS] -> packed K-major operand (see include/itcv_hip.h)."""
+    co, ci, ks = w4.shape[0], w4.shape[1], w4.shape[2]
+    wp = torch.empty(lib.itcv_conv2d_packed_weight_elems(co, ci, ks, for_dgrad), dtype=F32, device=w4.device)
+    call("itcv_conv2d_pack_weight", ptr(w4), ptr(wp), co, ci, ks, int(for_dgrad), stream())
+    return wp
+
+
+def conv_fwd_raw(x, wp, bias, B, Ci, H, W, Co, KS, up2):
+    y = torch.empty((B, Co, H, W), dtype=F32, device=x.device)
+    nws = lib.itcv_conv2d_fwd_workspace(B, Ci, H, W, Co, KS)
+    ws = _ws(nws, x.device) if nws else None
+    call("itcv_conv2d_fwd", ptr(x), ptr(wp), ptr(bias), ptr(y), B, Ci, H, W, Co, KS, int(up2), ptr(ws), nws, stream())
+    return y
+
+
+def conv_wgrad_raw(x, dy, B, Ci, H, W, Co, KS, up2, out=None, accumulate=False):
+    dw = out if out is not None else torch.empty((Co, Ci, KS, KS), dtype=F32, device=x.device)
+    nws = lib.itcv_conv2d_wgrad_workspace(B, Ci, H, W, Co, KS)
+    ws = _ws(nws, x.device)
+    call("itcv_conv2d_wgrad", ptr(x), ptr(dy), ptr(dw), B, Ci, H, W, Co, KS, int(up2), int(accumulate), ptr(ws), nws,
+         stream())
+    return dw
+
+
+def bias_grad_raw(dy, B, C, HW):
+    db = torch.empty((C,), dtype=F32, device=dy.device)
+    call("itcv_bias_grad", ptr(dy), ptr(db), B, C, HW, 0, stream())
+    return db
+
+
+class Conv2dFn(Function):
+    """nn.Conv2d(stride 1, padding KS//2) forward/backward; ``up2`` reads the input through a
+    virtual nearest x2 upsampling (models.py:284-286 fused into the consumer conv)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, up2):
+        x, weight = _f32c(x), _f32c(weight)
+        B, Ci, Hs, Ws = x.shape
+        Co, KS = weight.shape[0], weight.shape[2]
+        H, W = (Hs * 2, Ws * 2) if up2 else (Hs, Ws)
+        y = conv_fwd_raw(x, pack_weight(weight, 0), None if bias is None else _f32c(bias), B, Ci, H, W, Co, KS, up2)
+        ctx.save_for_backward(x, weight)
+        ctx.cfg = (B, Ci, H, W, Co, KS, up2, bias is not None)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        B, Ci, H, W, Co, KS, up2, has_bias = ctx.cfg
+        dy = _f32c(dy)
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = conv_fwd_raw(dy, pack_weight(weight, 1), None, B, Co, H, W, Ci, KS, False)
+            if up2:
+                lo = torch.empty((B, Ci, H // 2, W // 2), dtype=F32, device=dy.device)
+                call("itcv_upsample2_bwd", ptr(dx), ptr(lo), B * Ci, H // 2, W // 2, stream())
+                dx = lo
+        if ctx.needs_input_grad[1]:
+            dw = conv_wgrad_raw(x, dy, B, Ci, H, W, Co, KS, up2)
+        if has_bias and ctx.needs_input_grad[2]:
+            db = bias_grad_raw(dy, B, Co, H * W)
+        return dx, dw, db, None
+
+
+class LinearFn(Function):
+    """nn.Linear as the KS=1, H=W=1 case of the implicit-GEMM kernel."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        x, weight = _f32c(x), _f32c(weight)
+        B, Ci = x.shape
+        Co = weight.shape[0]
+        w4 = weight.view(Co, Ci, 1, 1)
+        y = conv_fwd_raw(x, pack_weight(w4, 0), None if bias is None else _f32c(bias), B, Ci, 1, 1, Co, 1, False)
+        ctx.save_for_backward(x, weight)
+        ctx.cfg = (B, Ci, Co, bias is not None)
+        return y.view(B, Co)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        B, Ci, Co, has_bias = ctx.cfg
+        dy = _f32c(dy)
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = conv_fwd_raw(dy, pack_weight(weight.view(Co, Ci, 1, 1), 1), None, B, Co, 1, 1, Ci, 1, False).view(B, Ci)
+        if ctx.needs_input_grad[1]:
+            dw = conv_wgrad_raw(x, dy, B, Ci, 1, 1, Co, 1, False).view(Co, Ci)
+        if has_bias and ctx.needs_input_grad[2]:
+            db = bias_grad_raw(dy, B, Co, 1)
+        return dx, dw, db
+
+
+# ------------------------------------------------------------------ BatchNorm + LeakyReLU (+pool)
+def _world(group):
+    return dist.get_world_size(group) if (group is not None and dist.is_initialized()) else 1
+
+
+class BnActFn(Function):
+    """y = pool(lrelu(BN_train(x) (+skip), slope)).  slope=1 -> plain BatchNorm; pool in {0,1}.
+    ``group``: process group for Sync-BN (moments all-reduced in fp64)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, skip, running_mean, running_var, nbt, eps, momentum, slope, pool, training,
+                group):
+        x, gamma, beta = _f32c(x), _f32c(gamma), _f32c(beta)
+        skip = None if skip is None else _f32c(skip)
+        B, C, H, W = x.shape
+        dev = x.device
+        mean = torch.empty((C,), dtype=F32, device=dev)
+        rstd = torch.empty((C,), dtype=F32, device=dev)
+        world = _world(group) if training else 1
+        if training:
+            nws = lib.itcv_bn_workspace(B, C, H * W)
+            ws = _ws(nws, dev)
+            sums = torch.empty((2 * C,), dtype=torch.float64, device=dev)
+            call("itcv_bn_moments", ptr(x), ptr(sums), B, C, H * W, ptr(ws), nws, stream())
+            if world > 1:
+                dist.all_reduce(sums, group=group)
+            call("itcv_bn_finalize", ptr(sums), float(B * H * W * world), float(eps), float(momentum),
+                 ptr(running_mean), ptr(running_var), ptr(nbt), ptr(mean), ptr(rstd), C, stream())
+        else:
+            call("itcv_bn_eval_stats", ptr(running_mean), ptr(running_var), float(eps), ptr(mean), ptr(rstd), C, stream())
+        oshape = (B, C, H // 2, W // 2) if pool else (B, C, H, W)
+        y = torch.empty(oshape, dtype=F32, device=dev)
+        call("itcv_bn_act_fwd", ptr(x), ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), ptr(skip), ptr(y), B, C, H, W,
+             float(slope), int(pool), stream())
+        ctx.save_for_backward(x, gamma, beta, mean, rstd, skip)
+        ctx.cfg = (B, C, H, W, float(slope), int(pool), bool(training), group, world)
+        ctx.mark_non_differentiable(*[t for t in (running_mean, running_var, nbt) if t is not None])
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        x, gamma, beta, mean, rstd, skip = ctx.saved_tensors
+        B, C, H, W, slope, pool, training, group, world = ctx.cfg
+        if not training:
+            raise abi.HipExtensionError("BatchNorm backward in eval mode is not part of the training hot path")
+        dy = _f32c(dy)
+        dev = x.device
+        nws = lib.itcv_bn_workspace(B, C, H * W)
+        ws = _ws(nws, dev)
+        local = torch.empty((2 * C,), dtype=torch.float64, device=dev)
+        call("itcv_bn_act_bwd_reduce", ptr(x), ptr(dy), ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), ptr(skip),
+             ptr(local), B, C, H, W, slope, pool, 0, ptr(ws), nws, stream())
+        total = local
+        if world > 1:
+            total = local.clone()
+            dist.all_reduce(total, group=group)
+        dx = torch.empty_like(x)
+        dskip = torch.empty_like(x) if (skip is not None and ctx.needs_input_grad[3]) else None
+        dgamma = torch.empty_like(gamma) if ctx.needs_input_grad[1] else None
+        dbeta = torch.empty_like(beta) if ctx.needs_input_grad[2] else None
+        call("itcv_bn_act_bwd_apply", ptr(x), ptr(dy), ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), ptr(skip),
+             ptr(total), ptr(local), float(B * H * W * world), ptr(dx), ptr(dskip), ptr(dgamma), ptr(dbeta), 0, B, C, H,
+             W, slope, pool, 0, stream())
+        return (dx, dgamma, dbeta, dskip) + (None,) * 9
+
+
+# ------------------------------------------------------------------ pointwise / resampling
+class LeakyReluFn(Function):
+    @staticmethod
+    def forward(ctx, x, slope):
+        x = _f32c(x)
+        y = torch.empty_like(x)
+        call("itcv_lrelu_fwd", ptr(x), ptr(y), x.numel(), float(slope), stream())
+        ctx.save_for_backward(x)
+        ctx.slope = float(slope)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        dy = _f32c(dy)
+        dx = torch.empty_like(x)
+        call("itcv_lrelu_bwd", ptr(x), ptr(dy), ptr(dx), x.numel(), ctx.slope, stream())
+        return dx, None
+
+
+class SigmoidFn(Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = _f32c(x)
+        y = torch.empty_like(x)
+        call("itcv_sigmoid_fwd", ptr(x), ptr(y), x.numel(), stream())
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        (y,) = ctx.saved_tensors
+        dy = _f32c(dy)
+        dx = torch.empty_like(y)
+        call("itcv_sigmoid_bwd", ptr(y), ptr(dy), ptr(dx), y.numel(), stream())
+        return dx
+
+
+class AvgPool2Fn(Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = _f32c(x)
+        B, C, H, W = x.shape
+        y = torch.empty((B, C, H // 2, W // 2), dtype=F32, device=x.device)
+        call("itcv_avgpool2_fwd", ptr(x), ptr(y), B * C, H, W, stream())
+        ctx.shape = (B, C, H, W)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        B, C, H, W = ctx.shape
+        dy = _f32c(dy)
+        dx = torch.empty((B, C, H, W), dtype=F32, device=dy.device)
+        call("itcv_avgpool2_bwd", ptr(dy), ptr(dx), B * C, H, W, stream())
+        return dx
+
+
+class Upsample2Fn(Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = _f32c(x)
+        B, C, H, W = x.shape
+        y = torch.empty((B, C, 2 * H, 2 * W), dtype=F32, device=x.device)
+        call("itcv_upsample2_fwd", ptr(x), ptr(y), B * C, H, W, stream())
+        ctx.shape = (B, C, H, W)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        B, C, H, W = ctx.shape
+        dy = _f32c(dy)
+        dx = torch.empty((B, C, H, W), dtype=F32, device=dy.device)
+        call("itcv_upsample2_bwd", ptr(dy), ptr(dx), B * C, H, W, stream())
+        return dx
+
+
+class AddFn(Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        a, b = _f32c(a), _f32c(b)
+        out = torch.empty_like(a)
+        call("itcv_add", ptr(a), ptr(b), ptr(out), a.numel(), stream())
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, g
+
+
+# ------------------------------------------------------------------ latent math
+class ReparamFn(Function):
+    """ops.py:166-185 with the N(0,1) draw as an explicit input."""
+
+    @staticmethod
+    def forward(ctx, mu, logvar, eps):
+        mu, logvar, eps = _f32c(mu), _f32c(logvar), _f32c(eps)
+        z = torch.empty_like(mu)
+        call("itcv_reparam_fwd", ptr(mu), ptr(logvar), ptr(eps), ptr(z), mu.numel(), stream())
+        ctx.save_for_backward(logvar, eps)
+        return z
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dz):
+        logvar, eps = ctx.saved_tensors
+        dz = _f32c(dz)
+        dmu, dlv = torch.empty_like(dz), torch.empty_like(dz)
+        call("itcv_reparam_bwd", ptr(dz), ptr(logvar), ptr(eps), ptr(dmu), ptr(dlv), dz.numel(), stream())
+        return dmu, dlv, None
+
+
+class KlRowsFn(Function):
+    """ops.py:161-163 -> [B]."""
+
+    @staticmethod
+    def forward(ctx, logvar, mu):
+        logvar, mu = _f32c(logvar), _f32c(mu)
+        B, D = logvar.shape
+        kl = torch.empty((B,), dtype=F32, device=mu.device)
+        call("itcv_kl_rows_fwd", ptr(logvar), ptr(mu), ptr(kl), B, D, stream())
+        ctx.save_for_backward(logvar, mu)
+        return kl
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        logvar, mu = ctx.saved_tensors
+        B, D = logvar.shape
+        g = _f32c(g)
+        dlv, dmu = torch.empty_like(logvar), torch.empty_like(mu)
+        call("itcv_kl_rows_bwd", ptr(g), ptr(logvar), ptr(mu), ptr(dlv), ptr(dmu), B, D, stream())
+        return dlv, dmu
+
+
+def tc_components(z, mu_all, logvar, dataset_size, row_offset=0, flags=abi.TC_LIVE):
+    """(prodm[Bl], logqz[Bl], lse[Bl,D]) of the fused pairwise-density / sampling kernel."""
+    z, mu_all, logvar = _f32c(z), _f32c(mu_all), _f32c(logvar)
+    Bl, D = z.shape
+    Bt = mu_all.shape[0]
+    dev = z.device
+    prodm = torch.empty((Bl,), dtype=F32, device=dev)
+    logqz = torch.empty((Bl,), dtype=F32, device=dev)
+    lse = torch.empty((Bl, D), dtype=F32, device=dev)
+    call("itcv_tc_fwd", ptr(z), ptr(mu_all), ptr(logvar), ptr(prodm), ptr(logqz), ptr(lse), Bl, Bt, int(row_offset), D,
+         int(dataset_size), int(flags), stream())
+    return prodm, logqz, lse
+
+
+class TcRowsFn(Function):
+    """ops.py:52-89 (live estimator) per local sample: tc[j] = log q(z_j) - sum_l log q(z_jl).
+    ``mu_all`` holds the means of the whole (global) batch; rows are the caller's samples."""
+
+    @staticmethod
+    def forward(ctx, z, mu_all, logvar, dataset_size, row_offset):
+        prodm, logqz, lse = tc_components(z, mu_all, logvar, dataset_size, row_offset, abi.TC_LIVE)
+        ctx.save_for_backward(_f32c(z), _f32c(mu_all), _f32c(logvar), logqz, lse)
+        ctx.cfg = (int(dataset_size), int(row_offset))
+        return logqz - prodm
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        z, mu_all, logvar, logqz, lse = ctx.saved_tensors
+        n, off = ctx.cfg
+        Bl, D = z.shape
+        Bt = mu_all.shape[0]
+        g = _f32c(g)
+        dz, dlv, dmu = torch.empty_like(z), torch.empty_like(logvar), torch.empty_like(mu_all)
+        nws = lib.itcv_tc_bwd_workspace(Bl, Bt)
+        ws = _ws(nws, z.device)
+        call("itcv_tc_bwd", ptr(g), ptr(z), ptr(mu_all), ptr(logvar), ptr(logqz), ptr(lse), ptr(dz), ptr(dmu), ptr(dlv),
+             Bl, Bt, off, D, n, abi.TC_LIVE, ptr(ws), nws, stream())
+        return dz, dmu, dlv, None, None
+
+
+def diag_logdensity_rows(z, mu, logvar):
+    z, mu, logvar = _f32c(z), _f32c(mu), _f32c(logvar)
+    B, D = z.shape
+    a = torch.empty((B,), dtype=F32, device=z.device)
+    b = torch.empty((B,), dtype=F32, device=z.device)
+    call("itcv_diag_logdensity_rows", ptr(z), ptr(mu), ptr(logvar), ptr(a), ptr(b), B, D, stream())
+    return a, b
+
+
+class ReconRowsFn(Function):
+    """ops.py:219-230: per-sample summed reconstruction error; x is treated as a constant."""
+
+    @staticmethod
+    def forward(ctx, x, recon, loss_type):
+        x, recon = _f32c(x), _f32c(recon)
+        B = recon.shape[0]
+        P = recon.numel() // B
+        rows = torch.empty((B,), dtype=F32, device=recon.device)
+        nws = lib.itcv_recon_workspace(B, P)
+        ws = _ws(nws, recon.device)
+        call("itcv_recon_rows_fwd", ptr(x), ptr(recon), ptr(rows), B, P, loss_type, ptr(ws), nws, stream())
+        ctx.save_for_backward(x, recon)
+        ctx.cfg = (B, P, loss_type)
+        return rows
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        x, recon = ctx.saved_tensors
+        B, P, lt = ctx.cfg
+        g = _f32c(g)
+        d = torch.empty_like(recon)
+        call("itcv_recon_rows_bwd", ptr(x), ptr(recon), ptr(g), ptr(d), B, P, lt, stream())
+        return None, d, None

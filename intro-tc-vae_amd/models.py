@@ -1,0 +1,309 @@
+"""Drop-in mirror of the reference's ``models`` module: SoftIntroVAE / Encoder / Decoder with the
+same constructor signatures, attribute names, parameter initialisation order and
+``state_dict`` keys as /root/reference/models.py:196-355, executing on hand-written HIP
+kernels (hipvae.functional -> libitcv_hip.so).
+
+Layer classes subclass the stock torch modules only to inherit their parameters, default
+initialisation and ``state_dict`` layout; every ``forward`` is replaced.  ``Encoder`` /
+``Decoder`` run a fused schedule over their children:
+
+    conv -> [BN statistics] -> BN-apply + LeakyReLU (+ 2x2 average pool)     (one pass)
+    nearest x2 upsample folded into the next convolution's im2col gather (never materialised)
+
+while ``self.main`` keeps the reference's child names (``main.0``, ``main.res_in_16.bn1`` ...)
+and still works layer by layer (``fused = False``), which is what the parity tests compare the
+fused schedule against.  There is no CPU path: a CPU tensor raises in hipvae.abi.
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+from hipvae import functional as HF
+from ops import reparameterize
+
+LRELU_SLOPE = 0.2
+
+
+# ------------------------------------------------------------------------------ layers
+class HipConv2d(nn.Conv2d):
+    """nn.Conv2d (stride 1, 'same' padding) on the implicit-GEMM MFMA kernel."""
+
+    def forward(self, x, up2=False):
+        return HF.Conv2dFn.apply(x, self.weight, self.bias, bool(up2))
+
+
+class HipLinear(nn.Linear):
+    def forward(self, x):
+        return HF.LinearFn.apply(x, self.weight, self.bias)
+
+
+class HipBatchNorm2d(nn.BatchNorm2d):
+    """BatchNorm2d with optional fused LeakyReLU / residual add / 2x2 average pool.
+    ``sync_group`` (a torch.distributed group) switches the statistics to Sync-BN."""
+
+    sync_group = None
+
+    def forward(self, x, slope=1.0, pool=False, skip=None):
+        return HF.BnActFn.apply(x, self.weight, self.bias, skip, self.running_mean, self.running_var,
+                                self.num_batches_tracked, self.eps, self.momentum, slope, bool(pool), self.training,
+                                self.sync_group)
+
+
+class HipLeakyReLU(nn.LeakyReLU):
+    def forward(self, x):
+        return HF.LeakyReluFn.apply(x, self.negative_slope)
+
+
+class HipAvgPool2d(nn.AvgPool2d):
+    def forward(self, x):
+        return HF.AvgPool2Fn.apply(x)
+
+
+class HipUpsample(nn.Upsample):
+    def forward(self, x):
+        return HF.Upsample2Fn.apply(x)
+
+
+class HipSigmoid(nn.Sigmoid):
+    def forward(self, x):
+        return HF.SigmoidFn.apply(x)
+
+
+def _conv(inc, outc, ks, bias=False):
+    return HipConv2d(inc, outc, kernel_size=ks, stride=1, padding=ks // 2, groups=1, bias=bias)
+
+
+def _expand(inc, outc):
+    return _conv(inc, outc, 1) if inc != outc else None
+
+
+# ------------------------------------------------------------------------------ blocks
+class ConvolutionalBlock(nn.Module):
+    """models.py:8-54: (conv3x3 -> BN(eps 1e-4) -> LeakyReLU 0.2) x 2.  ``conv_expand`` exists for
+    state_dict compatibility and, as in the reference, is never used by forward."""
+
+    def __init__(self, inc=64, outc=64, groups=1, scale=1.0):
+        super().__init__()
+        if groups != 1:
+            raise ValueError("groups != 1 is not supported by the HIP path")
+        midc = int(outc * scale)
+        self.eps = 1e-4
+        self.conv_expand = _expand(inc, outc)
+        self.conv1 = _conv(inc, midc, 3)
+        self.bn1 = HipBatchNorm2d(midc, eps=self.eps)
+        self.relu1 = HipLeakyReLU(LRELU_SLOPE, inplace=True)
+        self.conv2 = _conv(midc, outc, 3)
+        self.bn2 = HipBatchNorm2d(outc, eps=self.eps)
+        self.relu2 = HipLeakyReLU(LRELU_SLOPE, inplace=True)
+
+    def forward(self, x, pool=False, up2=False):
+        y = self.bn1(self.conv1(x, up2=up2), slope=LRELU_SLOPE)
+        return self.bn2(self.conv2(y), slope=LRELU_SLOPE, pool=pool)
+
+
+class ResidualBlock(nn.Module):
+    """models.py:57-115: conv-BN-LReLU-conv-BN, + (1x1-expanded) input, LReLU.  BN eps 1e-5."""
+
+    def __init__(self, inc=64, outc=64, groups=1, scale=1.0):
+        super().__init__()
+        if groups != 1:
+            raise ValueError("groups != 1 is not supported by the HIP path")
+        midc = int(outc * scale)
+        self.conv_expand = _expand(inc, outc)
+        self.conv1 = _conv(inc, midc, 3)
+        self.bn1 = HipBatchNorm2d(midc)
+        self.relu1 = HipLeakyReLU(LRELU_SLOPE, inplace=True)
+        self.conv2 = _conv(midc, outc, 3)
+        self.bn2 = HipBatchNorm2d(outc)
+        self.relu2 = HipLeakyReLU(LRELU_SLOPE, inplace=True)
+
+    def forward(self, x, pool=False, up2=False):
+        if self.conv_expand is not None:
+            skip = self.conv_expand(x, up2=up2)
+        else:
+            skip = HF.Upsample2Fn.apply(x) if up2 else x
+        y = self.bn1(self.conv1(x, up2=up2), slope=LRELU_SLOPE)
+        return self.bn2(self.conv2(y), slope=LRELU_SLOPE, pool=pool, skip=skip)
+
+
+class Conv2dBatchNorm(nn.Module):
+    """models.py:118-138."""
+
+    def __init__(self, in_size, out_size, kernel_size, stride, padding=0, groups=1):
+        super().__init__()
+        if stride != 1 or groups != 1 or padding != kernel_size // 2:
+            raise ValueError("only stride 1 / 'same' padding / groups 1 run on the HIP path")
+        self.conv = _conv(in_size, out_size, kernel_size)
+        self.eps = 1e-4
+        self.batch_norm = HipBatchNorm2d(out_size, eps=self.eps)
+        self.relu = HipLeakyReLU(LRELU_SLOPE, inplace=True)
+
+    def forward(self, x, up2=False):
+        return self.batch_norm(self.conv(x, up2=up2), slope=LRELU_SLOPE)
+
+
+class InceptionResnetBlock(nn.Module):
+    """models.py:141-182: two 1x1 branches, concat, biased 1x1 conv, + (expanded) input, LReLU."""
+
+    def __init__(self, inc=64, outc=64, groups=1, scale=1.0):
+        super().__init__()
+        self.eps = 1e-4
+        midc = int(outc * scale)
+        assert outc % 2 == 0
+        self.conv_expand = _expand(inc, outc)
+        self.branch_0 = Conv2dBatchNorm(inc, outc // 2, kernel_size=1, stride=1, groups=groups)
+        self.branch_1 = nn.Sequential(
+            Conv2dBatchNorm(inc, midc, kernel_size=1, stride=1, groups=groups),
+            Conv2dBatchNorm(midc, outc // 2, kernel_size=1, stride=1, groups=groups),
+        )
+        self.conv = _conv(outc, outc, 1, bias=True)
+        self.relu = HipLeakyReLU(LRELU_SLOPE, inplace=True)
+
+    def forward(self, x, pool=False, up2=False):
+        if up2:
+            x = HF.Upsample2Fn.apply(x)
+        skip = self.conv_expand(x) if self.conv_expand is not None else x
+        y = torch.cat((self.branch_0(x), self.branch_1(x)), dim=1)
+        y = self.relu(HF.AddFn.apply(self.conv(y), skip))
+        return HF.AvgPool2Fn.apply(y) if pool else y
+
+
+_BLOCKS = {"conv": ConvolutionalBlock, "res": ResidualBlock, "inception": InceptionResnetBlock}
+
+
+def get_conv_class(arch):
+    """models.py:185-193."""
+    try:
+        return _BLOCKS[arch]
+    except KeyError:
+        raise ValueError() from None
+
+
+# ------------------------------------------------------------------------------ encoder / decoder
+class Encoder(nn.Module):
+    """models.py:196-244."""
+
+    def __init__(self, arch="res", cdim=3, zdim=512, channels=(64, 128, 256, 512, 512, 512), image_size=256):
+        super().__init__()
+        self.conv_block = get_conv_class(arch)
+        self.zdim, self.cdim, self.image_size = zdim, cdim, image_size
+        self.fused = True
+        cc = channels[0]
+        self.main = nn.Sequential(
+            _conv(cdim, cc, 5),
+            HipBatchNorm2d(cc, eps=1e-4),
+            HipLeakyReLU(LRELU_SLOPE, inplace=True),
+            HipAvgPool2d(2),
+        )
+        sz = image_size // 2
+        self._stages = []  # (block name, pooled afterwards)
+        for ch in channels[1:]:
+            self.main.add_module(f"res_in_{sz}", self.conv_block(cc, ch, scale=1.0))
+            self.main.add_module(f"down_to_{sz // 2}", HipAvgPool2d(2))
+            self._stages.append((f"res_in_{sz}", True))
+            cc, sz = ch, sz // 2
+        self.main.add_module(f"res_in_{sz}", self.conv_block(cc, cc, scale=1.0))
+        self._stages.append((f"res_in_{sz}", False))
+        self.conv_output_size = torch.Size((cc, sz, sz))
+        num_fc_features = cc * sz * sz
+        self._warm_batchnorm(arch)
+        print("conv shape: ", self.conv_output_size)
+        print("num fc features: ", num_fc_features)
+        self.fc = HipLinear(num_fc_features, 2 * zdim)
+
+    def _warm_batchnorm(self, arch):
+        """The reference sizes its fc layer by pushing a zero image through ``main`` in train mode
+        (models.py:229,235-238), which leaves every encoder BatchNorm with running_var = 0.9 and
+        num_batches_tracked = 1.  With bias-free convolutions the activations of that pass are
+        identically zero, so the buffers are set directly (shape arithmetic replaces the pass)."""
+        if arch == "inception":
+            raise NotImplementedError("inception blocks: encoder BatchNorm warm-up state not implemented yet")
+        for m in self.main.modules():
+            if isinstance(m, nn.BatchNorm2d):
+                m.running_var.fill_(0.9)
+                m.num_batches_tracked.fill_(1)
+
+    def forward(self, x):
+        if self.fused:
+            y = self.main[1](self.main[0](x), slope=LRELU_SLOPE, pool=True)
+            for name, pooled in self._stages:
+                y = getattr(self.main, name)(y, pool=pooled)
+        else:
+            y = self.main(x)
+        y = self.fc(y.reshape(x.size(0), -1))
+        mu, logvar = y.chunk(2, dim=1)
+        return mu, logvar
+
+
+class Decoder(nn.Module):
+    """models.py:247-298."""
+
+    def __init__(self, arch="res", cdim=3, zdim=512, channels=(64, 128, 256, 512, 512, 512), image_size=256,
+                 conv_input_size=None):
+        super().__init__()
+        self.conv_block = get_conv_class(arch)
+        self.cdim, self.image_size = cdim, image_size
+        self.fused = True
+        cc = channels[-1]
+        self.conv_input_size = conv_input_size
+        num_fc_features = cc * 4 * 4 if conv_input_size is None else int(math.prod(conv_input_size))
+        if conv_input_size is None:
+            self.conv_input_size = torch.Size((cc, 4, 4))
+        self.fc = nn.Sequential(HipLinear(zdim, num_fc_features), HipLeakyReLU(LRELU_SLOPE, inplace=True))
+        sz = int(math.sqrt(num_fc_features // cc))
+        self.main = nn.Sequential()
+        self._stages = []
+        for ch in channels[::-1]:
+            self.main.add_module(f"res_in_{sz}", self.conv_block(cc, ch, scale=1.0))
+            self.main.add_module(f"up_to_{sz * 2}", HipUpsample(scale_factor=2, mode="nearest"))
+            self._stages.append(f"res_in_{sz}")
+            cc, sz = ch, sz * 2
+        self.main.add_module(f"res_in_{sz}", self.conv_block(cc, cc, scale=1.0))
+        self._stages.append(f"res_in_{sz}")
+        self.main.add_module("predict", _conv(cc, cdim, 5, bias=True))
+        self.main.add_module("sigmoid", HipSigmoid())
+
+    def forward(self, z):
+        z = z.reshape(z.size(0), -1)
+        y = self.fc(z).view(z.size(0), *self.conv_input_size)
+        if self.fused:
+            for k, name in enumerate(self._stages):
+                y = getattr(self.main, name)(y, up2=k > 0)  # the upsample before block k folds into its conv
+            y = self.main.sigmoid(self.main.predict(y))
+        else:
+            y = self.main(y)
+        return y
+
+
+class SoftIntroVAE(nn.Module):
+    """models.py:301-355."""
+
+    def __init__(self, arch="res", cdim=3, zdim=512, channels=(64, 128, 256, 512, 512, 512), image_size=256):
+        super().__init__()
+        self.zdim: int = zdim
+        self.cdim: int = cdim
+        self.encoder = Encoder(arch, cdim, zdim, channels, image_size)
+        self.decoder = Decoder(arch, cdim, zdim, channels, image_size,
+                               conv_input_size=self.encoder.conv_output_size)
+
+    def forward(self, x, deterministic=False):
+        mu, logvar = self.encode(x)
+        z = mu if deterministic else reparameterize(mu, logvar)
+        return mu, logvar, z, self.decode(z)
+
+    def sample(self, z):
+        return self.decode(z)
+
+    def sample_with_noise(self, num_samples=1, device=torch.device("cpu")):
+        return self.decode(torch.randn(num_samples, self.zdim).to(device))
+
+    def encode(self, x):
+        return self.encoder(x)
+
+    def decode(self, z):
+        return self.decoder(z)
+
+    def set_fused(self, flag):
+        self.encoder.fused = self.decoder.fused = bool(flag)
+        return self

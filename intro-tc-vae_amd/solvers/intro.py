@@ -1,0 +1,99 @@
+"""IntroSolver: the Soft-Intro VAE step (/root/reference/solvers/intro.py:18-196) on HIP kernels.
+
+Per call: 5 encoder and 8 decoder forward passes, two backward passes, two optimiser updates --
+the schedule, the draw order of the six N(0,1) tensors and the frozen-half / stale-gradient
+clip semantics follow the reference line by line (cited inline); the arithmetic is all in
+libitcv_hip.so and the host reads the five returned scalars back in ONE transfer.
+"""
+from typing import Optional
+
+import torch
+from torch import Tensor
+
+from hipvae import ddp
+from ops import noise, reparameterize
+from solvers.vae import VAESolver
+
+
+class IntroSolver(VAESolver):
+    def __init__(self, dataset, model, batch_size: int, optimizer_e, optimizer_d, recon_loss_type: str,
+                 beta_kl: float, beta_rec: float, beta_neg: float, gamma_r: float, device: torch.device,
+                 use_amp: bool, grad_scaler, writer=None, test_iter: int = 1000, clip: Optional[float] = None):
+        super().__init__(dataset, model, batch_size, optimizer_e, optimizer_d, recon_loss_type, beta_kl, beta_rec,
+                         device, use_amp, grad_scaler, writer, test_iter, clip)
+        self.beta_neg = beta_neg
+        self.gamma_r = gamma_r
+
+    def _exp_elbo(self, rec_rows: Tensor, kl_rows: Tensor) -> Tensor:
+        """intro.py:102-103  mean_j exp(-2 * scale * (rec_j + kl_j))."""
+        while rec_rows.dim() > 1:
+            rec_rows = rec_rows.sum(-1)
+        return (-2 * self.scale * (rec_rows + kl_rows)).exp().mean()
+
+    def train_step(self, batch: Tensor, cur_iter: int) -> dict:
+        if batch.dim() == 3:
+            batch = batch.unsqueeze(0)
+        model, scale = self.model, self.scale
+        noise_batch = noise((batch.size(0), model.zdim), self.device)               # intro.py:61
+        real = batch.to(self.device)
+
+        # ================= update E (decoder frozen) ======================== intro.py:65-116
+        self._set_trainable(encoder=True, decoder=False)
+        fake = model.sample(noise_batch)
+        real_mu, real_logvar = model.encode(real)
+        z = reparameterize(real_mu, real_logvar)
+        rec = model.decoder(z)
+        loss_rec = self.compute_rec_loss(real, rec, reduction="mean")
+        loss_e_real_kl = self.compute_kl_loss(z, real_mu, real_logvar, write=True)
+        rec_mu, rec_logvar, z_rec, rec_rec = model(rec.detach())
+        fake_mu, fake_logvar, z_fake, rec_fake = model(fake.detach())
+        kl_rec = self.compute_kl_loss(z_rec, rec_mu, rec_logvar, reduce="none", beta=self.beta_neg)
+        kl_fake = self.compute_kl_loss(z_fake, fake_mu, fake_logvar, reduce="none", beta=self.beta_neg)
+        expelbo_rec = self._exp_elbo(self.compute_rec_loss(rec, rec_rec, reduction="none"), kl_rec)
+        expelbo_fake = self._exp_elbo(self.compute_rec_loss(fake, rec_fake, reduction="none"), kl_fake)
+        loss_e = scale * (loss_rec + loss_e_real_kl) + 0.25 * (expelbo_rec + expelbo_fake)
+        self._backward(loss_e, ("encoder",))
+        norm_e = self._clip()
+        self._step("encoder")
+
+        # ================= update D (encoder frozen) ======================== intro.py:118-160
+        self._set_trainable(encoder=False, decoder=True)
+        fake = model.sample(noise_batch)
+        rec = model.decoder(z.detach())
+        loss_rec = self.compute_rec_loss(real, rec, reduction="mean", write=True)
+        rec_mu, rec_logvar = model.encode(rec)
+        z_rec = reparameterize(rec_mu, rec_logvar)
+        fake_mu, fake_logvar = model.encode(fake)
+        z_fake = reparameterize(fake_mu, fake_logvar)
+        rec_rec = model.decode(z_rec.detach())
+        rec_fake = model.decode(z_fake.detach())
+        g = self.gamma_r * self.beta_rec
+        loss_rec_rec = self.compute_rec_loss(rec.detach(), rec_rec, reduction="mean", beta=g)
+        loss_fake_rec = self.compute_rec_loss(fake.detach(), rec_fake, reduction="mean", beta=g)
+        loss_d_rec_kl = self.compute_kl_loss(z_rec, rec_mu, rec_logvar)
+        loss_d_fake_kl = self.compute_kl_loss(z_fake, fake_mu, fake_logvar)
+        loss_d = scale * (loss_rec + (loss_d_rec_kl + loss_d_fake_kl) * 0.5 + (loss_rec_rec + loss_fake_rec) * 0.5)
+        self._backward(loss_d, ("decoder",))
+        norm_d = self._clip()
+        self._step("decoder")
+
+        # ================= one read-back, NaN check, logging ================ intro.py:162-196
+        stats = torch.stack([loss_e.detach(), loss_d.detach(), loss_e_real_kl.detach(), loss_rec.detach(),
+                             expelbo_fake.detach(), loss_d_fake_kl.detach()])
+        ddp.mean_scalars_(stats)
+        v_e, v_d, v_kl, v_rec, v_expf, v_dfkl, v_ne, v_nd = self._read(*stats.unbind(0), norm_e, norm_d)
+        if v_e != v_e or v_d != v_d:
+            raise RuntimeError
+        if self.writer:
+            self.write_scalars(cur_iter, losses=dict(r_loss=v_rec, kl_loss=v_kl, expelbo_f=v_expf),
+                               diff_kl=v_dfkl - v_kl)
+            if self.clip:
+                self.writer.add_scalars("total_norm", {"E": v_ne, "D": v_nd}, global_step=cur_iter)
+            self.writer.add_scalar("lossE", v_e, global_step=cur_iter)
+            self.writer.add_scalar("lossD", v_d, global_step=cur_iter)
+            self.write_gradient_norm(cur_iter)
+            self.write_images(real, fake, cur_iter)
+            self.write_disentanglemnt_scores(cur_iter)
+            self.writer.flush()
+        return {"loss_enc": v_e, "loss_dec": v_d, "loss_kl": v_kl, "loss_rec": v_rec,
+                "L2": max(v_ne, v_nd) if self.clip else None}

@@ -1,0 +1,194 @@
+"""VAESolver with the reference's constructor / hook / ``train_step`` surface
+(/root/reference/solvers/vae.py:26-136), running the step on HIP kernels.
+
+Shared machinery for all four solvers lives here: flat gradient buffers, the fused
+clip-norm + Adam tail, the single end-of-step host read-back and the data-parallel hooks.
+"""
+from typing import Optional
+
+import torch
+from torch import Tensor
+
+from hipvae import ddp
+from hipvae.flat import FlatGroup, clip_grad_norm, plain_adam_hparams
+from ops import kl_divergence, reconstruction_loss
+from utils import SingletonWriter
+
+try:  # present when dropped into the reference tree; the hot path does not need them
+    from dataset import DisentanglementDataset
+except Exception:  # noqa: BLE001
+    class DisentanglementDataset:  # type: ignore
+        pass
+
+
+class VAESolver:
+    def __init__(self, dataset, model, batch_size: int, optimizer_e, optimizer_d, recon_loss_type: str,
+                 beta_kl: float, beta_rec: float, device: torch.device, use_amp: bool, grad_scaler,
+                 writer=None, test_iter: int = 1000, clip: Optional[float] = None):
+        self.dataset = dataset
+        if isinstance(dataset, DisentanglementDataset):
+            try:
+                from evaluation.generator import LatentGenerator
+                self.latent_generator = LatentGenerator(dataset, device)
+            except Exception:  # noqa: BLE001  evaluation stack is outside the hot path
+                self.latent_generator = None
+        self.model = model
+        self.batch_size = batch_size
+        self.optimizer_e, self.optimizer_d = optimizer_e, optimizer_d
+        self.beta_kl, self.beta_rec = beta_kl, beta_rec
+        self.device = device
+        self.use_amp, self.grad_scaler = use_amp, grad_scaler      # stored, unused (as in the reference)
+        self.writer, self.test_iter, self.clip = writer, test_iter, clip
+        self.recon_loss_type = recon_loss_type
+        self.scale = 1 / (self.model.cdim * self.model.encoder.image_size ** 2)   # solvers/vae.py:61
+        self._flat = {}
+
+    # ---- overridable loss hooks (solvers/vae.py:63-87) -----------------------------------
+    def compute_kl_loss(self, z: Optional[Tensor], mu: Tensor, logvar: Tensor, reduce: str = "mean",
+                        beta: float = None, write: bool = False) -> Tensor:
+        if beta is None:
+            beta = self.beta_kl
+        kl = kl_divergence(logvar, mu, reduce=reduce)
+        if write:
+            self.write_scalar(SingletonWriter().cur_iter, "kl_loss_unscaled", kl)
+        return beta * kl
+
+    def compute_rec_loss(self, x, recon_x, reduction="sum", beta: float = None, write: bool = False) -> Tensor:
+        if beta is None:
+            beta = self.beta_rec
+        rec = reconstruction_loss(x, recon_x, self.recon_loss_type, reduction)
+        if write:
+            self.write_scalar(SingletonWriter().cur_iter, "r_loss_unscaled", rec)
+        return beta * rec
+
+    # ---- optimiser tail shared by all solvers ----------------------------------------------
+    def _group(self, part) -> FlatGroup:
+        params = list(getattr(self.model, part).parameters())
+        g = self._flat.get(part)
+        if g is None or not g.owns(params):
+            g = self._flat[part] = FlatGroup(params)
+        return g
+
+    def _set_trainable(self, encoder: bool, decoder: bool):
+        for p in self.model.encoder.parameters():
+            p.requires_grad = encoder
+        for p in self.model.decoder.parameters():
+            p.requires_grad = decoder
+
+    def _backward(self, loss, parts):
+        """optimizer.zero_grad() of ``parts`` + loss.backward() + gradient averaging over ranks."""
+        groups = [self._group(p) for p in parts]
+        for g in groups:
+            g.zero_grad()
+        loss.backward()
+        for g in groups:
+            ddp.average_(g.flat_g)
+
+    def _clip(self):
+        """clip_grad_norm_ over ALL parameters with a gradient, stale frozen-half gradients included
+        (solvers/intro.py:113-115,157-159).  Returns the norm as a device scalar (or None)."""
+        if not self.clip:
+            return None
+        return clip_grad_norm([self._group("encoder"), self._group("decoder")], self.clip)
+
+    def _step(self, part):
+        opt = self.optimizer_e if part == "encoder" else self.optimizer_d
+        hp = plain_adam_hparams(opt)
+        if hp is None:
+            opt.step()                       # non-Adam optimiser supplied by the caller: torch's own update
+        else:
+            self._group(part).adam_step(*hp)
+
+    @staticmethod
+    def _read(*scalars):
+        """One device->host transfer for every scalar the step returns (the reference syncs >= 6x)."""
+        vals = torch.stack([s.detach().reshape(()).float() if s is not None else torch.zeros((), device=scalars[0].device)
+                            for s in scalars])
+        return vals.tolist()
+
+    # ---- solvers/vae.py:89-136 ---------------------------------------------------------------
+    def train_step(self, batch: Tensor, cur_iter: int) -> dict:
+        if batch.dim() == 3:
+            batch = batch.unsqueeze(0)
+        real = batch.to(self.device)
+        self._set_trainable(True, True)
+        mu, logvar, z, rec = self.model(real)
+        loss_rec = self.compute_rec_loss(real, rec, reduction="mean", write=True)
+        loss_kl = self.compute_kl_loss(z, mu, logvar, write=True)
+        loss = self.scale * (loss_rec + loss_kl)
+        self._backward(loss, ("decoder", "encoder"))
+        norm = self._clip()
+        self._step("encoder")
+        self._step("decoder")
+        stats = torch.stack([loss.detach(), loss_kl.detach(), loss_rec.detach()])
+        ddp.mean_scalars_(stats)
+        v_loss, v_kl, v_rec, v_norm = self._read(stats[0], stats[1], stats[2], norm)
+        if v_loss != v_loss:
+            raise RuntimeError
+        if self.writer:
+            self.write_scalars(cur_iter, losses=dict(r_loss=v_rec, kl_loss=v_kl))
+            if self.clip:
+                self.writer.add_scalar("total_norm", v_norm, global_step=cur_iter)
+            self.write_gradient_norm(cur_iter)
+            self._write_images_helper(real, cur_iter)
+            self.write_disentanglemnt_scores(cur_iter)
+            self.writer.flush()
+        # the reference leaves L2 unbound when clip is falsy (vae.py:135); None is returned instead
+        return {"loss_enc": v_loss, "loss_dec": v_loss, "loss_kl": v_kl, "loss_rec": v_rec,
+                "L2": v_norm if self.clip else None}
+
+    # ---- TensorBoard side channel (solvers/vae.py:138-254); all no-ops without a writer ------
+    def _write_images_helper(self, batch, cur_iter):
+        if self.writer is not None and cur_iter % self.test_iter == 0:
+            noise = torch.randn(size=(batch.size(0), self.model.zdim), device=self.device)
+            with torch.no_grad():
+                fake = self.model.sample(noise)
+            self.write_images(batch, fake, cur_iter)
+
+    def write_images(self, batch, fake_batch, cur_iter):
+        if self.writer is not None and cur_iter % self.test_iter == 0:
+            with torch.no_grad():
+                _, _, _, rec_det = self.model(batch, deterministic=True)
+            k = min(batch.size(0), 16)
+            grid = torch.cat([batch[:k], rec_det[:k], fake_batch[:k]], dim=0).data.cpu()
+            self.writer.add_images("reconstructions", grid, global_step=cur_iter)
+
+    def write_gradient_norm(self, cur_iter: int):
+        grads = [p.grad.detach().norm(2) for p in self.model.encoder.fc.parameters() if p.grad is not None]
+        if grads:
+            self.writer.add_scalar("fc_grad_norm", torch.stack(grads).norm(2).item(), global_step=cur_iter)
+
+    def write_scalar(self, cur_iter: int, tag: str, value: Tensor):
+        if self.writer and value.dim() == 0:
+            self.writer.add_scalar(tag, value.data.item(), global_step=cur_iter)
+
+    def write_scalars(self, cur_iter: int, losses: dict, **kwargs):
+        if self.writer is not None:
+            self.write_losses(cur_iter, losses)
+            for name, value in kwargs.items():
+                self.writer.add_scalar(name, value, global_step=cur_iter)
+
+    def write_losses(self, cur_iter: int, losses: dict):
+        if self.writer is not None:
+            self.writer.add_scalars("losses", losses, global_step=cur_iter)
+
+    def write_disentanglemnt_scores(self, cur_iter: int, num_samples: int = 10000):
+        """Delegates to the reference's CPU evaluation package when it is importable; out of scope here."""
+        if self.writer is None or not isinstance(self.dataset, DisentanglementDataset) or cur_iter % self.test_iter:
+            return
+        try:
+            from evaluation import metrics as M
+        except Exception:  # noqa: BLE001
+            return
+        was_training = self.model.training
+        self.model.eval()
+        n = num_samples if len(self.dataset) >= num_samples else len(self.dataset) // 2
+        kw = dict(latent_generator=self.latent_generator, model=self.model, num_samples=n, batch_size=self.batch_size)
+        for fn in (M.write_bvae_score, M.write_dci_score, M.write_mig_score, M.write_mod_expl_score):
+            fn(self.writer, cur_iter, **kw)
+        if was_training:
+            self.model.train()
+
+    def write_gradient_flow(self, cur_iter, named_parameters):
+        """Matplotlib figure of per-layer gradient magnitudes in the reference; not reproduced."""
+        return None

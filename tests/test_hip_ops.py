@@ -1,0 +1,321 @@
+"""GPU parity tests of every C-ABI kernel family (through hipvae.functional -> ctypes ->
+libitcv_hip.so) against plain PyTorch fp64/fp32 CPU references and the pinned oracle.
+
+Tolerances (fp32 path, stated per check): convolutions / linear 2e-5 of the output scale
+(fp32 fma chains vs an fp64 reference), statistics 1e-5, latent TC terms 1e-4 relative
+(the bar north_star sets for ELBO / KL terms)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.fixture(scope="module")
+def HF():
+    from hipvae import functional
+    return functional
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def rel_err(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+CONV_CASES = [
+    # B, Ci, H, W, Co, KS, up2
+    (2, 3, 16, 16, 8, 5, False),      # stem-like, K = 75 (tail in K)
+    (3, 8, 8, 8, 16, 3, False),
+    (2, 16, 12, 20, 40, 3, False),    # non power-of-two spatial, M tail
+    (4, 32, 4, 4, 32, 3, False),      # tiny spatial: N = 64 < tile
+    (2, 64, 16, 16, 3, 5, False),     # predict-like: Co = 3
+    (2, 24, 8, 8, 130, 3, False),     # two M tiles with tail
+    (5, 96, 1, 1, 70, 1, False),      # linear as 1x1
+    (2, 8, 16, 16, 8, 3, True),       # fused nearest upsample
+    (1, 12, 8, 8, 20, 1, True),
+    (2, 512, 4, 4, 64, 3, False),     # deep K = 4608 -> split-K path
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_forward_backward(HF, case):
+    B, Ci, H, W, Co, KS, up2 = case
+    g = torch.Generator().manual_seed(hash(case) % 1000)
+    hs, ws = (H // 2, W // 2) if up2 else (H, W)
+    x = torch.randn(B, Ci, hs, ws, generator=g)
+    w = torch.randn(Co, Ci, KS, KS, generator=g) / (Ci * KS * KS) ** 0.5
+    b = torch.randn(Co, generator=g)
+    dy = torch.randn(B, Co, H, W, generator=g)
+    xr, wr, br = (t.double().requires_grad_(True) for t in (x, w, b))
+    xin = F.interpolate(xr, scale_factor=2, mode="nearest") if up2 else xr
+    yr = F.conv2d(xin, wr, br, padding=KS // 2)
+    yr.backward(dy.double())
+    xd, wd, bd = (t.to(dev()).requires_grad_(True) for t in (x, w, b))
+    y = HF.Conv2dFn.apply(xd, wd, bd, up2)
+    y.backward(dy.to(dev()))
+    torch.cuda.synchronize()
+    assert rel_err(y, yr) < 2e-5
+    assert rel_err(xd.grad, xr.grad) < 2e-5
+    assert rel_err(wd.grad, wr.grad) < 2e-5
+    assert rel_err(bd.grad, br.grad) < 2e-5
+
+
+def test_conv_full_size_layer(HF):
+    """One full-resolution layer of the 64x64 configuration (64->64 @64x64, 3x3; B=16 keeps the
+    fp64 CPU reference to a few seconds) -- many N tiles, K = 65536 in the weight gradient."""
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(16, 64, 64, 64, generator=g)
+    w = torch.randn(64, 64, 3, 3, generator=g) / 24
+    dy = torch.randn(16, 64, 64, 64, generator=g)
+    xd, wd = x.to(dev()).requires_grad_(True), w.to(dev()).requires_grad_(True)
+    y = HF.Conv2dFn.apply(xd, wd, None, False)
+    y.backward(dy.to(dev()))
+    xr, wr = x.double().requires_grad_(True), w.double().requires_grad_(True)
+    yr = F.conv2d(xr, wr, padding=1)
+    yr.backward(dy.double())
+    assert rel_err(y, yr) < 2e-5
+    assert rel_err(xd.grad, xr.grad) < 2e-5
+    assert rel_err(wd.grad, wr.grad) < 5e-5     # K = 262144-term sums in fp32 slabs
+
+
+def test_linear(HF):
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(64, 512, generator=g)
+    w = torch.randn(40, 512, generator=g) / 22
+    b = torch.randn(40, generator=g)
+    dy = torch.randn(64, 40, generator=g)
+    xr, wr, br = (t.double().requires_grad_(True) for t in (x, w, b))
+    F.linear(xr, wr, br).backward(dy.double())
+    xd, wd, bd = (t.to(dev()).requires_grad_(True) for t in (x, w, b))
+    y = HF.LinearFn.apply(xd, wd, bd)
+    y.backward(dy.to(dev()))
+    assert rel_err(y, F.linear(xr, wr, br)) < 2e-5
+    assert rel_err(xd.grad, xr.grad) < 2e-5
+    assert rel_err(wd.grad, wr.grad) < 2e-5
+    assert rel_err(bd.grad, br.grad) < 2e-5
+
+
+@pytest.mark.parametrize("pool,skip,slope", [(False, False, 0.2), (True, False, 0.2), (False, True, 0.2),
+                                              (True, True, 0.2), (False, False, 1.0)])
+@pytest.mark.parametrize("shape", [(4, 6, 8, 8), (3, 5, 4, 12), (16, 32, 16, 16)])
+def test_batchnorm_act(HF, shape, pool, skip, slope):
+    B, C, H, W = shape
+    g = torch.Generator().manual_seed(B * 100 + C)
+    x = torch.randn(B, C, H, W, generator=g) * 2 + 0.5
+    gamma, beta = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g)
+    sk = torch.randn(B, C, H, W, generator=g) if skip else None
+    rm, rv = torch.randn(C, generator=g), torch.rand(C, generator=g) + 0.5
+    oshape = (B, C, H // 2, W // 2) if pool else shape
+    dy = torch.randn(*oshape, generator=g)
+    eps = 1e-4
+    # fp64 reference
+    xr, gr, br = (t.double().requires_grad_(True) for t in (x, gamma, beta))
+    skr = sk.double().requires_grad_(True) if skip else None
+    rmr, rvr = rm.double().clone(), rv.double().clone()
+    u = F.batch_norm(xr, rmr, rvr, gr, br, training=True, momentum=0.1, eps=eps)
+    if skip:
+        u = u + skr
+    yr = F.leaky_relu(u, slope)
+    if pool:
+        yr = F.avg_pool2d(yr, 2)
+    yr.backward(dy.double())
+    d = dev()
+    xd, gd, bd = (t.to(d).requires_grad_(True) for t in (x, gamma, beta))
+    skd = sk.to(d).requires_grad_(True) if skip else None
+    rmd, rvd, nbt = rm.to(d), rv.to(d), torch.zeros((), dtype=torch.long, device=d)
+    y = HF.BnActFn.apply(xd, gd, bd, skd, rmd, rvd, nbt, eps, 0.1, slope, pool, True, None)
+    y.backward(dy.to(d))
+    assert rel_err(y, yr) < 1e-5
+    assert rel_err(rmd, rmr) < 1e-5 and rel_err(rvd, rvr) < 1e-5 and int(nbt) == 1
+    assert rel_err(xd.grad, xr.grad) < 2e-5
+    assert rel_err(gd.grad, gr.grad) < 2e-5 and rel_err(bd.grad, br.grad) < 2e-5
+    if skip:
+        assert rel_err(skd.grad, skr.grad) < 1e-6
+    # eval mode uses the running statistics
+    ye = HF.BnActFn.apply(x.to(d), gamma.to(d), beta.to(d), None, rmd, rvd, nbt, eps, 0.1, slope, pool, False, None)
+    ue = F.leaky_relu(F.batch_norm(x.double(), rmd.double().cpu(), rvd.double().cpu(), gamma.double(), beta.double(),
+                                   training=False, eps=eps), slope)
+    assert rel_err(ye, F.avg_pool2d(ue, 2) if pool else ue) < 1e-5
+
+
+def test_bn_upsampled_gradient_mode(HF):
+    """itcv_bn_act_bwd_* with up2=1 (gradient arriving at x2 resolution) == upsample adjoint + plain."""
+    from hipvae.abi import call, lib, ptr, stream
+    B, C, H, W = 3, 4, 6, 8
+    g = torch.Generator().manual_seed(9)
+    d = dev()
+    x = torch.randn(B, C, H, W, generator=g).to(d)
+    gamma, beta = (torch.rand(C, generator=g) + 0.5).to(d), torch.randn(C, generator=g).to(d)
+    mean, rstd = x.mean((0, 2, 3)), 1.0 / (x.var((0, 2, 3), unbiased=False) + 1e-4).sqrt()
+    dy_hi = torch.randn(B, C, 2 * H, 2 * W, generator=g).to(d)
+    dy_lo = dy_hi.view(B, C, H, 2, W, 2).sum((3, 5)).contiguous()
+    outs = []
+    for dy, up2 in ((dy_hi, 1), (dy_lo, 0)):
+        nws = lib.itcv_bn_workspace(B, C, H * W)
+        ws = torch.empty(nws, dtype=torch.uint8, device=d)
+        sums = torch.empty(2 * C, dtype=torch.float64, device=d)
+        call("itcv_bn_act_bwd_reduce", ptr(x), ptr(dy), ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), None, ptr(sums),
+             B, C, H, W, 0.2, 0, up2, ptr(ws), nws, stream())
+        dx = torch.empty_like(x)
+        call("itcv_bn_act_bwd_apply", ptr(x), ptr(dy), ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), None, ptr(sums),
+             None, float(B * H * W), ptr(dx), None, None, None, 0, B, C, H, W, 0.2, 0, up2, stream())
+        outs.append((sums.clone(), dx))
+    assert rel_err(outs[0][0], outs[1][0]) < 1e-6
+    assert rel_err(outs[0][1], outs[1][1]) < 1e-5
+
+
+def test_pointwise_and_resampling(HF):
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(3, 5, 8, 12, generator=g)
+    for fn, ref in ((lambda t: HF.LeakyReluFn.apply(t, 0.2), lambda t: F.leaky_relu(t, 0.2)),
+                    (HF.SigmoidFn.apply, torch.sigmoid),
+                    (HF.AvgPool2Fn.apply, lambda t: F.avg_pool2d(t, 2)),
+                    (HF.Upsample2Fn.apply, lambda t: F.interpolate(t, scale_factor=2, mode="nearest"))):
+        xr = x.double().requires_grad_(True)
+        yr = ref(xr)
+        dy = torch.randn(*yr.shape, generator=g)
+        yr.backward(dy.double())
+        xd = x.to(dev()).requires_grad_(True)
+        y = fn(xd)
+        y.backward(dy.to(dev()))
+        assert rel_err(y, yr) < 1e-6 and rel_err(xd.grad, xr.grad) < 1e-6
+    a, b = torch.randn(1000, generator=g), torch.randn(1000, generator=g)
+    assert rel_err(HF.AddFn.apply(a.to(dev()), b.to(dev())), a + b) == 0
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
+def test_latent_against_golden(HF, tag):
+    """Reference-generated vectors (tests/golden/ops.npz): KL, reparameterise, MSS/MWS, TC, the full
+    decomposition and the gradients of (beta-1)TC + KL, with both clamps of ops.py:18,21 firing."""
+    import ops
+    G = np.load(os.path.join(GOLDEN, "ops.npz"))
+    B, D, N = (int(v) for v in G[f"{tag}_BDN"])
+    d = dev()
+    z, mu, lv, eps = (torch.from_numpy(G[f"{tag}_{k}"]).to(d) for k in ("z", "mu", "logvar", "eps"))
+    T = lambda k: torch.from_numpy(G[f"{tag}_{k}"])  # noqa: E731
+    assert rel_err(HF.ReparamFn.apply(mu, lv, eps), T("reparam")) < 1e-6
+    assert rel_err(ops.kl_no_reduce(lv, mu), T("kl_none")) < 1e-5
+    assert rel_err(ops.kl_divergence(lv, mu, "mean"), T("kl_mean")) < 1e-5
+    pm, lq = ops.tc_components(z, mu, lv, N)
+    assert rel_err(pm, T("mss_prodm")) < 1e-4 and rel_err(lq, T("mss_logqz")) < 1e-4
+    pm, lq = ops.tc_components(z, mu, lv, N, weighted=True)
+    assert rel_err(pm, T("mws_prodm")) < 1e-4 and rel_err(lq, T("mws_logqz")) < 1e-4
+    assert rel_err(ops.total_correlation(z, mu, lv, N, "none"), T("tc_none")) < 1e-4
+    assert rel_err(ops.total_correlation(z, mu, lv, N, "mean"), T("tc_mean")) < 1e-4
+    mi, tc, dw = ops.tc_decomposition(z, mu, lv, N)
+    assert rel_err(mi, T("full_mi")) < 1e-4 and rel_err(tc, T("full_tc")) < 1e-4 and rel_err(dw, T("full_dwkl")) < 1e-4
+    for beta, bt in ((512.0, "512p0"), (0.5, "0p5")):
+        zz, mm, ll = (t.clone().requires_grad_(True) for t in (z, mu, lv))
+        loss = (beta - 1.0) * ops.total_correlation(zz, mm, ll, N, "mean") + ops.kl_divergence(ll, mm, "mean")
+        loss.backward()
+        assert rel_err(loss, T(f"tckl_b{bt}")) < 1e-4
+        assert rel_err(zz.grad, T(f"tckl_b{bt}_dz")) < 1e-4
+        assert rel_err(mm.grad, T(f"tckl_b{bt}_dmu")) < 1e-4
+        assert rel_err(ll.grad, T(f"tckl_b{bt}_dlogvar")) < 1e-4
+    zz, mm, ll = (t.clone().requires_grad_(True) for t in (z, mu, lv))
+    w = T("tcw_w").to(d)
+    (w * ops.total_correlation(zz, mm, ll, N, "none")).sum().backward()
+    assert rel_err(zz.grad, T("tcw_dz")) < 1e-4
+    assert rel_err(mm.grad, T("tcw_dmu")) < 1e-4
+    assert rel_err(ll.grad, T("tcw_dlogvar")) < 1e-4
+
+
+def test_tc_sharded_rows_equal_full_batch(HF):
+    """Rows [r*Bl, (r+1)*Bl) with row_offset and the full mu reproduce the full-batch estimator
+    (what each data-parallel rank computes), including the special logW entries."""
+    import ops
+    g = torch.Generator().manual_seed(4)
+    B, D, N, R = 32, 24, 5000, 4
+    d = dev()
+    mu = torch.randn(B, D, generator=g).to(d)
+    lv = (-3 + 2 * torch.randn(B, D, generator=g)).to(d)
+    z = (mu + torch.randn(B, D, generator=g).to(d) * (0.5 * lv).exp())
+    full = ops.total_correlation(z, mu, lv, N, "none")
+    Bl = B // R
+    parts = [ops.total_correlation(z[r * Bl:(r + 1) * Bl], mu[r * Bl:(r + 1) * Bl], lv[r * Bl:(r + 1) * Bl], N, "none",
+                                   mu_all=mu, row_offset=r * Bl) for r in range(R)]
+    assert rel_err(torch.cat(parts), full) < 1e-6
+
+
+def test_reconstruction(HF):
+    import ops
+    G = np.load(os.path.join(GOLDEN, "ops.npz"))
+    d = dev()
+    x, xr = torch.from_numpy(G["rec_x"]).to(d), torch.from_numpy(G["rec_xr"]).to(d)
+    for lt in ("mse", "l1", "bce"):
+        for red in ("sum", "mean", "none"):
+            assert rel_err(ops.reconstruction_loss(x, xr, lt, red), torch.from_numpy(G[f"rec_{lt}_{red}"])) < 1e-5
+        xg = xr.clone().requires_grad_(True)
+        (torch.from_numpy(G[f"rec_{lt}_w"]).to(d) * ops.reconstruction_loss(x, xg, lt, "none")).sum().backward()
+        assert rel_err(xg.grad, torch.from_numpy(G[f"rec_{lt}_dxr"])) < 1e-5
+    # known answers of the reference's tests/test_ops.py:10-43
+    x0, x1 = torch.zeros(3, device=d), torch.tensor([1.0, 2.0, 4.0], device=d)
+    assert ops.reconstruction_loss(x0, x1, "mse", "sum").item() == 21
+    assert ops.reconstruction_loss(x0, x1, "mse", "mean").item() == 7
+    assert ops.reconstruction_loss(x0, x1, "mse", "none").tolist() == [1, 4, 16]
+    assert ops.reconstruction_loss(x0, x1, "l1", "sum").item() == 7
+    assert ops.reconstruction_loss(x0, x1, "l1", "mean").item() == pytest.approx(7 / 3)
+    with pytest.raises(NotImplementedError):
+        ops.reconstruction_loss(x0, x1, "huber", "sum")
+    with pytest.raises(NotImplementedError):
+        ops.reconstruction_loss(x0, x1, "mse", "avg")
+    # large rows exercise the split reduction
+    g = torch.Generator().manual_seed(8)
+    a, b = torch.rand(8, 3, 64, 64, generator=g), torch.rand(8, 3, 64, 64, generator=g)
+    ref = ((a.double() - b.double()) ** 2).reshape(8, -1).sum(1)
+    assert rel_err(ops.reconstruction_loss(a.to(d), b.to(d), "mse", "none"), ref) < 1e-6
+
+
+def test_ops_shapes_like_reference_tests():
+    """Shape checks of the reference's tests/test_ops.py:48-66 on the HIP path."""
+    import ops
+    d = dev()
+    mu = torch.zeros(3, device=d).view(1, 3)
+    logvar = torch.tensor([[1.0, 2.0, 4.0]], device=d)
+    assert ops.reparameterize(mu, logvar).shape == mu.shape
+    mu2 = torch.zeros(2, 2, device=d)
+    lv2 = torch.tensor([[1.0, 2.0], [4.0, 8.0]], device=d)
+    assert ops.kl_divergence(mu2, lv2, reduce="sum").dim() == 0
+    assert ops.kl_divergence(mu2, lv2, reduce="none").dim() == 1
+
+
+def test_adam_and_clip_match_torch():
+    from hipvae.flat import FlatGroup, clip_grad_norm
+    g = torch.Generator().manual_seed(6)
+    shapes = [(7, 3, 3, 3), (13,), (5, 11), (1,)]
+    ps_ref = [torch.nn.Parameter(torch.randn(*s, generator=g)) for s in shapes]
+    ps = [torch.nn.Parameter(p.detach().clone().to(dev())) for p in ps_ref]
+    opt = torch.optim.Adam(ps_ref, lr=2e-4)
+    grp = FlatGroup(ps)
+    for step in range(3):
+        grads = [torch.randn(*s, generator=g) * (50.0 if step == 1 else 0.01) for s in shapes]
+        for p, pr, gr in zip(ps, ps_ref, grads):
+            pr.grad = gr.clone()
+            p.grad.copy_(gr.to(dev()))
+        n_ref = torch.nn.utils.clip_grad_norm_(ps_ref, 100.0)
+        n = clip_grad_norm([grp], 100.0)
+        assert abs(float(n) - float(n_ref)) <= 1e-5 * float(n_ref)
+        for p, pr in zip(ps, ps_ref):
+            assert rel_err(p.grad, pr.grad) < 1e-6
+        opt.step()
+        grp.adam_step(2e-4)
+        for p, pr in zip(ps, ps_ref):
+            assert float((p.detach().cpu() - pr.detach()).abs().max()) < 2e-9 + 1e-6 * 2e-4
+
+
+def test_errors_are_loud():
+    from hipvae import abi
+    with pytest.raises(abi.HipExtensionError):
+        abi.ptr(torch.zeros(3))
+    with pytest.raises(RuntimeError):
+        abi.call("itcv_conv2d_pack_weight", None, None, 1, 1, 7, 0, None)
+    assert "itcv_conv2d_pack_weight" in abi.last_error()
