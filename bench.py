@@ -1,0 +1,213 @@
+#!/usr/bin/env python3
+"""Headline benchmark: images/sec of one IntroTCSovler.train_step (Soft-Intro beta-TC-VAE step:
+5 encoder + 8 decoder forwards, 2 backwards, 2 Adam updates) on synthetic 64x64x3 batches,
+z_dim=128, batch 64 per GPU, conv architecture -- BASELINE.json configs[1] (c2), fp32.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+One process per GPU; N>1 shards the batch (weak scaling, 64 images per GPU) with a flat RCCL
+all-reduce of the trained half's gradients per phase, an all-gather of mu for the full-batch TC
+estimator and Sync-BN moments.  Rank 0 prints ONE JSON line.  Inputs are resident in HBM before
+the timed region; the timed region is bracketed by barrier + synchronize on both sides and the
+maximum over ranks is reported.
+
+Extra objects on the line:
+  roofline      dominant kernel (implicit-GEMM conv on the fp32 matrix cores): algorithmic FLOP of
+                its launches / their HIP-event durations, measured live during the timed steps on
+                the launch stream; peak = 157.3 TFLOP/s dense fp32 MFMA (MI355X_MICROARCH.md).
+  cpu_baseline  the CPU oracle (oracle/, a PyTorch-CPU port pinned to the reference by golden
+                vectors) timed on the host cores on a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (os.path.join(ROOT, "intro-tc-vae_amd"), ROOT):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+CFG = dict(cdim=3, zdim=128, channels=(64, 128, 256, 512), image_size=64)
+B_PER_GPU = 64
+HP = dict(beta_kl=0.5, beta_rec=0.75, beta_neg=512.0, gamma_r=1e-8, clip=100.0, lr=2e-4, dataset=10000)
+PEAK_F32_MFMA_TFLOPS = 157.3
+# 13*Fe + 19*Fd = 48.237 GFLOP per image per intro-tc step (2*MAC, conv+linear)
+STEP_GFLOP_PER_IMAGE = 48.237
+
+
+class _DS:
+    def __len__(self):
+        return HP["dataset"]
+
+
+def host_cores():
+    """CPU cores this process may actually use: affinity mask, capped by the cgroup CPU quota (the
+    GPU box hands a one-GPU job a 16-core share of a much larger host)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, int(os.environ.get("ITCV_CPU_THREADS", n))))
+
+
+def log(msg):
+    print(f"[bench] {msg}", file=sys.stderr, flush=True)
+
+
+def cpu_baseline():
+    """Times the CPU oracle's intro-TC step on this host: a B=16 warm-up step, then ONE timed
+    step at the full B=64 (about 10-20 s of CPU work on 8-16 cores)."""
+    import models
+    from oracle.network import Net
+    from oracle.steps import Trainer
+    cores = host_cores()
+    torch.set_num_threads(cores)
+    log(f"cpu baseline on {cores} threads (os.cpu_count()={os.cpu_count()})")
+    torch.manual_seed(0)
+    import contextlib
+    import io
+    with contextlib.redirect_stdout(io.StringIO()):
+        model = models.SoftIntroVAE(arch="conv", **CFG)
+    state = {k: v.clone() for k, v in model.state_dict().items()}
+    tr = Trainer("intro_tc", Net("conv", state=state, **CFG), dataset_size=HP["dataset"], beta_kl=HP["beta_kl"],
+                 beta_rec=HP["beta_rec"], beta_neg=HP["beta_neg"], gamma_r=HP["gamma_r"], clip=HP["clip"], lr=HP["lr"])
+    g = torch.Generator().manual_seed(1234)
+
+    def one(batch):
+        x = torch.rand(batch, 3, 64, 64, generator=g)
+        draws = [torch.randn(batch, CFG["zdim"], generator=g) for _ in range(6)]
+        t0 = time.perf_counter()
+        tr.step(x, draws)
+        return time.perf_counter() - t0
+
+    log(f"cpu warm-up step B=16: {one(16):.1f} s")
+    t = one(B_PER_GPU)
+    log(f"cpu timed step B={B_PER_GPU}: {t:.1f} s")
+    return {"value": round(B_PER_GPU / t, 3), "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": f"1 intro-tc step at B={B_PER_GPU} ({t:.1f} s) after a B=16 warm-up step; "
+                      "oracle/ (PyTorch-CPU fp32 port of the reference step, pinned by golden vectors)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-sync-bn", action="store_true", help="per-rank BatchNorm statistics (throughput mode)")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} processes (WORLD_SIZE={world})")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    import contextlib
+    import io
+    import models
+    from hipvae import ddp
+    from hipvae import functional as HF
+    from solvers.intro_tc import IntroTCSovler
+
+    if world > 1:
+        ddp.init(sync_bn=not args.no_sync_bn)
+    torch.manual_seed(0)
+    with contextlib.redirect_stdout(io.StringIO()):
+        model = models.SoftIntroVAE(arch="conv", **CFG)
+    model = model.to(dev).train()
+    opt_e = torch.optim.Adam(model.encoder.parameters(), lr=HP["lr"])
+    opt_d = torch.optim.Adam(model.decoder.parameters(), lr=HP["lr"])
+    solver = IntroTCSovler(_DS(), model, B_PER_GPU, opt_e, opt_d, "mse", HP["beta_kl"], HP["beta_rec"],
+                           HP["beta_neg"], HP["gamma_r"], dev, False, None, clip=HP["clip"])
+    g = torch.Generator().manual_seed(1000 + rank)
+    batches = [torch.rand(B_PER_GPU, 3, 64, 64, generator=g).to(dev) for _ in range(4)]   # resident in HBM
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    last = None
+    for i in range(args.warmup):
+        last = solver.train_step(batches[i % len(batches)], i)
+        if rank == 0:
+            log(f"warm-up step {i}: {last}")
+    sync()
+    HF.LaunchProfile.begin()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        last = solver.train_step(batches[i % len(batches)], args.warmup + i)
+    sync()
+    elapsed = time.perf_counter() - t0
+    records = HF.LaunchProfile.end()
+    if rank == 0:
+        log(f"timed {args.steps} steps in {elapsed:.3f} s")
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t)
+
+    # ---- roofline of the dominant kernel from the live HIP-event records -------------------
+    buckets = {}
+    for label, flop, s, e in records:
+        b = buckets.setdefault(label, [0, 0.0, 0.0])
+        b[0] += 1
+        b[1] += flop
+        b[2] += s.elapsed_time(e) * 1e-3
+    conv_time = sum(b[2] for b in buckets.values())
+    conv_flop = sum(b[1] for b in buckets.values())
+    dom_label, dom = max(buckets.items(), key=lambda kv: kv[1][2])
+    achieved = dom[1] / dom[2] * 1e-12
+    roofline = {
+        "bound": "mfma", "kernel": dom_label, "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS,
+        "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+        "launches_per_step": dom[0] / args.steps, "avg_launch_us": round(dom[2] / dom[0] * 1e6, 2),
+        "algorithmic_gflop_per_launch": round(dom[1] / dom[0] * 1e-9, 3),
+        "all_conv_kernels": {"achieved": round(conv_flop / conv_time * 1e-12, 2),
+                             "share_of_step_time": round(conv_time / elapsed, 3)},
+    }
+
+    images = B_PER_GPU * world * args.steps
+    value = images / elapsed
+    out = {
+        "metric": "images/sec (64x64x3, z=128, bs=64) intro-TC step", "value": round(value, 2), "unit": "images/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "c2: IntroTCSovler.train_step, conv arch, 64x64x3, z_dim=128, channels (64,128,256,512), "
+                               f"batch {B_PER_GPU}/GPU, Adam lr 2e-4, clip 100, N=10000",
+                   "global_batch": B_PER_GPU * world, "parallelism": f"dp{world}" if world > 1 else "single",
+                   "sync_bn": bool(world > 1 and not args.no_sync_bn)},
+        "step_tflop": round(STEP_GFLOP_PER_IMAGE * B_PER_GPU * world * 1e-3, 3),
+        "whole_step_mfma_frac": round(value * STEP_GFLOP_PER_IMAGE * 1e-3 / (PEAK_F32_MFMA_TFLOPS * world), 4),
+        "last_step": last,
+        "roofline": roofline,
+    }
+    if rank == 0:
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+            out["gpu_over_cpu"] = round(value / out["cpu_baseline"]["value"], 1)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -55,6 +55,10 @@ int itcv_conv2d_fwd(const float* x, const float* wp, const float* bias, float* y
 size_t itcv_conv2d_wgrad_workspace(int B, int Ci, int H, int W, int Co, int KS);
 int itcv_conv2d_wgrad(const float* x, const float* dy, float* dw, int B, int Ci, int H, int W,
                       int Co, int KS, int up2, int accumulate, void* ws, size_t ws_bytes, void* stream);
+/* Kernel instantiation a call resolves to, for profiling buckets: bits 0-7 block rows BM,
+ * 8-15 KS, 16 up2, 20-31 split-K factor. */
+int itcv_conv2d_fwd_variant(int B, int Ci, int H, int W, int Co, int KS, int up2);
+int itcv_conv2d_wgrad_variant(int B, int Ci, int H, int W, int Co, int KS, int up2);
 /* db[C] (+)= sum_{b,hw} dy[b][c][hw]  (bias gradients: models.py:290 predict, :233/:270 Linear) */
 int itcv_bias_grad(const float* dy, float* db, int B, int C, int HW, int accumulate, void* stream);
 

@@ -563,6 +563,19 @@ int itcv_conv2d_wgrad(const float* x, const float* dy, float* dw, int B, int Ci,
   return 0;
 }
 
+// Which kernel instantiation / decomposition a call resolves to (for profiling buckets):
+//   bits 0-7 block rows BM, 8-15 KS, 16 up2, 20-31 split-K factor
+int itcv_conv2d_fwd_variant(int B, int Ci, int H, int W, int Co, int KS, int up2) {
+  if (B <= 0 || Ci <= 0 || H <= 0 || W <= 0 || Co <= 0) return -1;
+  const FwdPlan p = plan_fwd(B, Ci, H, W, Co, KS);
+  return p.bm | (KS << 8) | ((up2 ? 1 : 0) << 16) | (p.splits << 20);
+}
+int itcv_conv2d_wgrad_variant(int B, int Ci, int H, int W, int Co, int KS, int up2) {
+  if (B <= 0 || Ci <= 0 || H <= 0 || W <= 0 || Co <= 0) return -1;
+  const WgPlan p = plan_wgrad(B, Ci, H, W, Co, KS);
+  return p.bm | (KS << 8) | ((up2 ? 1 : 0) << 16) | (p.splits << 20);
+}
+
 int itcv_bias_grad(const float* dy, float* db, int B, int C, int HW, int accumulate, void* stream) {
   ITCV_REQUIRE(dy && db && B > 0 && C > 0 && HW > 0, "itcv_bias_grad");
   hipLaunchKernelGGL(bias_grad_kernel, dim3(C), dim3(256), 0, S(stream), dy, db, B, C, HW, accumulate);

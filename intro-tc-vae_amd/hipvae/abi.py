@@ -33,6 +33,8 @@ SIGNATURES = {
     "itcv_conv2d_fwd": (i32, [p, p, p, p, i32, i32, i32, i32, i32, i32, i32, p, sz, p]),
     "itcv_conv2d_wgrad_workspace": (sz, [i32] * 6),
     "itcv_conv2d_wgrad": (i32, [p, p, p, i32, i32, i32, i32, i32, i32, i32, i32, p, sz, p]),
+    "itcv_conv2d_fwd_variant": (i32, [i32] * 7),
+    "itcv_conv2d_wgrad_variant": (i32, [i32] * 7),
     "itcv_bias_grad": (i32, [p, p, i32, i32, i32, i32, p]),
     "itcv_bn_workspace": (sz, [i32, i32, i32]),
     "itcv_bn_moments": (i32, [p, p, i32, i32, i32, p, sz, p]),

@@ -37,21 +37,63 @@ def pack_weight(w4, for_dgrad):
     return wp
 
 
+class LaunchProfile:
+    """Optional HIP-event bracket around every implicit-GEMM launch (bench.py's roofline leg).
+    Events are recorded on the stream the kernel is launched on (torch's current stream)."""
+    active = None  # list of (kernel label, algorithmic flop, start event, end event)
+
+    @classmethod
+    def begin(cls):
+        cls.active = []
+
+    @classmethod
+    def end(cls):
+        rec, cls.active = cls.active, None
+        return rec
+
+
+def _label(kind, v):
+    return f"conv_{kind}_kernel<KS={(v >> 8) & 255},BM={v & 255},up2={(v >> 16) & 1}>/splitK={v >> 20}"
+
+
+def _profiled(kind, variant, flop, launch):
+    if LaunchProfile.active is None:
+        return launch()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    out = launch()
+    e.record()
+    LaunchProfile.active.append((_label(kind, variant), flop, s, e))
+    return out
+
+
 def conv_fwd_raw(x, wp, bias, B, Ci, H, W, Co, KS, up2):
     y = torch.empty((B, Co, H, W), dtype=F32, device=x.device)
     nws = lib.itcv_conv2d_fwd_workspace(B, Ci, H, W, Co, KS)
     ws = _ws(nws, x.device) if nws else None
-    call("itcv_conv2d_fwd", ptr(x), ptr(wp), ptr(bias), ptr(y), B, Ci, H, W, Co, KS, int(up2), ptr(ws), nws, stream())
-    return y
+
+    def launch():
+        call("itcv_conv2d_fwd", ptr(x), ptr(wp), ptr(bias), ptr(y), B, Ci, H, W, Co, KS, int(up2), ptr(ws), nws, stream())
+        return y
+    if LaunchProfile.active is None:
+        return launch()
+    return _profiled("fwd", lib.itcv_conv2d_fwd_variant(B, Ci, H, W, Co, KS, int(up2)),
+                     2.0 * B * H * W * Co * Ci * KS * KS, launch)
 
 
 def conv_wgrad_raw(x, dy, B, Ci, H, W, Co, KS, up2, out=None, accumulate=False):
     dw = out if out is not None else torch.empty((Co, Ci, KS, KS), dtype=F32, device=x.device)
     nws = lib.itcv_conv2d_wgrad_workspace(B, Ci, H, W, Co, KS)
     ws = _ws(nws, x.device)
-    call("itcv_conv2d_wgrad", ptr(x), ptr(dy), ptr(dw), B, Ci, H, W, Co, KS, int(up2), int(accumulate), ptr(ws), nws,
-         stream())
-    return dw
+
+    def launch():
+        call("itcv_conv2d_wgrad", ptr(x), ptr(dy), ptr(dw), B, Ci, H, W, Co, KS, int(up2), int(accumulate), ptr(ws),
+             nws, stream())
+        return dw
+    if LaunchProfile.active is None:
+        return launch()
+    return _profiled("wgrad", lib.itcv_conv2d_wgrad_variant(B, Ci, H, W, Co, KS, int(up2)),
+                     2.0 * B * H * W * Co * Ci * KS * KS, launch)
 
 
 def bias_grad_raw(dy, B, C, HW):
