@@ -36,10 +36,11 @@ const char* itcv_last_error(void);
  * Replaces nn.Conv2d / nn.Linear forward+backward: models.py:28-47 (3x3 blocks), :213
  * (5x5 stem), :290 (5x5 predict, with bias), :233 / :270 (Linear == KS 1, H=W=1).
  *
- * Weights are consumed in a packed, zero-padded K-major layout wp[Kp][Mp] (Kp = K rounded up
- * to 16, Mp = M rounded up to 32):
- *   for_dgrad = 0:  M = Co, K = Ci*KS*KS, wp[(ci*KK+tap)][co] = w[co][ci][tap]
- *   for_dgrad = 1:  M = Ci, K = Co*KS*KS, wp[(co*KK+tap)][ci] = w[co][ci][KK-1-tap]
+ * Weights are consumed in a packed, zero-padded, K-major layout wp[KS*KS*Cp][Mp] with the
+ * reduction index ordered TAP-MAJOR, k = tap*Cp + c (Cp = reduction channels rounded up to 16,
+ * Mp = M rounded up to the 32/64/128-row tile the kernel picks for M):
+ *   for_dgrad = 0:  M = Co, c = ci:  wp[tap*Cp + ci][co] = w[co][ci][tap]
+ *   for_dgrad = 1:  M = Ci, c = co:  wp[tap*Cp + co][ci] = w[co][ci][KK-1-tap]
  * so that the data-gradient is the same kernel run on dy with the roles of Ci/Co swapped. */
 size_t itcv_conv2d_packed_weight_elems(int Co, int Ci, int KS, int for_dgrad);
 int itcv_conv2d_pack_weight(const float* w, float* wp, int Co, int Ci, int KS, int for_dgrad,
@@ -60,7 +61,9 @@ int itcv_conv2d_wgrad(const float* x, const float* dy, float* dw, int B, int Ci,
 int itcv_conv2d_fwd_variant(int B, int Ci, int H, int W, int Co, int KS, int up2);
 int itcv_conv2d_wgrad_variant(int B, int Ci, int H, int W, int Co, int KS, int up2);
 /* db[C] (+)= sum_{b,hw} dy[b][c][hw]  (bias gradients: models.py:290 predict, :233/:270 Linear) */
-int itcv_bias_grad(const float* dy, float* db, int B, int C, int HW, int accumulate, void* stream);
+size_t itcv_bias_grad_workspace(int B, int C, int HW);
+int itcv_bias_grad(const float* dy, float* db, int B, int C, int HW, int accumulate, void* ws,
+                   size_t ws_bytes, void* stream);
 
 /* ---- BatchNorm2d (+ LeakyReLU, + AvgPool2d(2)) ---------------------------------------
  * Replaces nn.BatchNorm2d(eps) -> nn.LeakyReLU(0.2) [-> nn.AvgPool2d(2)]: models.py:37-38,48-49,

@@ -4,23 +4,40 @@
 // /root/reference/models.py:28-47,213,233,270,290.
 //
 //   forward / data-gradient:  C[M][N] = A[K][M]^T * im2col(X)[K][N]
-//        M = output channels, N = B*H*W (pixel index, contiguous in NCHW), K = Cin*KS*KS
-//        A = packed weights (K-major, zero padded), gathered B operand read with hardware
-//        bounds-checked buffer loads (padding and tile tails come back as 0).
+//        M = output channels, N = B*H*W (pixel index, contiguous in NCHW),
+//        K ordered TAP-MAJOR: k = tap*Cip + ci (Cip = channels padded to 16), so one 16-deep
+//        K-tile is ONE filter tap x 16 consecutive channels: the im2col gather of a tile is a
+//        single shifted window -- one bounds decision and one address per thread per tile, the
+//        16 rows differ only by a scalar channel stride (buffer_load soffset).
+//        A = packed weights (K-major, zero padded to the tile), read with unconditional float4s.
 //   weight-gradient:          C[M][N] = sum_k dY[M][k] * im2col(X)[N][k]
-//        M = Co, N = Ci*KS*KS (== the OIHW layout of dW), k = (b,h,w); split-K over k with
-//        fp32 slabs and a deterministic reduce (bitwise reproducible, no atomics).
+//        M = Co, N = (tap, ci) tap-major, k = (b,h,w); split-K over k with fp32 slabs and a
+//        deterministic reduce that also transposes to the OIHW layout of dW (no atomics).
 //
-// Tiling: 256 threads = 4 waves; each wave owns TMxTN tiles of 32x32 accumulators (AGPRs);
-// LDS tiles are K-major so every ds_read_b32 of an MFMA operand is 32 consecutive floats per
-// half-wave (conflict free).  Global->register->LDS software pipeline with two LDS buffers and
-// one barrier per K-tile.  blockIdx -> tile mapping keeps tiles that share an im2col panel on
-// one XCD (blocks b and b+8 share an XCD's L2).
+// Padding and tile tails are zero-filled by the buffer unit: an invalid element gets a voffset
+// >= 2^31 > num_records, which the hardware range check turns into 0 (no branches in the loop).
+//
+// Tiling: 256 threads = 4 waves; each wave owns TMxTN tiles of 32x32 accumulators (AGPRs); LDS
+// tiles are K-major so every ds_read_b32 of an MFMA operand is 32 consecutive floats per
+// half-wave (conflict free); operand fragments are double-buffered in registers across the
+// K-steps.  Global->register->LDS software pipeline with two LDS buffers and one barrier per
+// K-tile.  blockIdx -> tile mapping keeps tiles that share an im2col panel on one XCD.
 #include "common.h"
 
 namespace itcv {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr uint32_t kOobBase = 0x80000000u;  // + any soffset < 2^31 stays out of range
+
+__device__ __forceinline__ float buf_load_s(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff) {
+  // soffset must live in an SGPR: state the wave-uniformity explicitly or hipcc wraps the load in a
+  // waterfall loop whenever register pressure parked the (loop-invariant) value in a VGPR
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, __builtin_amdgcn_readfirstlane(soff), 0));
+}
+
+__host__ __device__ inline int tile_rows_for(int M) { return M <= 32 ? 32 : (M <= 64 ? 64 : 128); }
 
 struct ConvArgs {
   const float* x;
@@ -28,16 +45,42 @@ struct ConvArgs {
   const float* bias;
   float* y;
   int B, Ci, H, W, Co;
-  int Mp, K, N;
+  int Cip, Mp, N;
   int mt, nt;
-  int ktiles, ktiles_per_split;
+  int ktiles, ktiles_per_split, cpt;  // cpt = K-tiles per tap = Cip/16
   uint32_t x_bytes;
   size_t slab_stride;
 };
 
-template <int KS, int BM, int BN, int WM, int WN, bool UP2>
+// One MFMA K-tile worth of work on LDS buffers As[BK][PA], Bs[BK][PB] (K-major)
+template <int BK, int PA, int PB, int TM, int TN>
+__device__ __forceinline__ void mfma_tile(const float* __restrict__ Ab, const float* __restrict__ Bb,
+                                          f32x16 (&acc)[TM][TN]) {
+  float av[2][TM], bv[2][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) av[0][i] = Ab[i * 32];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) bv[0][j] = Bb[j * 32];
+#pragma unroll
+  for (int s = 0; s < BK / 2; ++s) {
+    const int c = s & 1, nx = c ^ 1;
+    if (s + 1 < BK / 2) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i) av[nx][i] = Ab[(2 * s + 2) * PA + i * 32];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) bv[nx][j] = Bb[(2 * s + 2) * PB + j * 32];
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[c][i], bv[c][j], acc[i][j], 0, 0, 0);
+  }
+}
+
+template <int KS, int BM, int BN, int WM, int WN, bool UP2, bool CI_TAIL>
 __global__ __launch_bounds__(WM* WN * 64) void conv_fwd_kernel(ConvArgs a) {
-  constexpr int NT = WM * WN * 64, BK = 16, KK = KS * KS, P = KS / 2;
+  constexpr int NT = WM * WN * 64, BK = 16, P = KS / 2;
   constexpr int WTM = BM / WM, WTN = BN / WN, TM = WTM / 32, TN = WTN / 32;
   constexpr int PA = BM + 4, PB = BN + 4;
   static_assert(NT % BN == 0 && BN % 64 == 0, "B gather rows must be wave-uniform");
@@ -58,7 +101,8 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_fwd_kernel(ConvArgs a) {
 
   // ---- per-thread im2col column: pixel n -> (image, h, w), tap validity mask ------------
   constexpr int BROWS = NT / BN, BL = BK / BROWS;
-  const int nl = t % BN, kr0 = t / BN;
+  const int nl = t % BN;
+  const int kr0 = __builtin_amdgcn_readfirstlane(t / BN);  // wave-uniform: row offsets live in SGPRs
   const int n = n0 + nl;
   const bool nvalid = n < a.N;
   int bi = 0, h = 0, w = 0;
@@ -70,50 +114,48 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_fwd_kernel(ConvArgs a) {
   }
   uint32_t tapmask = 0;
 #pragma unroll
-  for (int tap = 0; tap < KK; ++tap) {
+  for (int tap = 0; tap < KS * KS; ++tap) {
     const int dh = tap / KS - P, dw = tap % KS - P;
     if (nvalid && (unsigned)(h + dh) < (unsigned)H && (unsigned)(w + dw) < (unsigned)W) tapmask |= 1u << tap;
   }
-  const int tbase = bi * a.Ci * HWs + (UP2 ? 0 : h * W + w);
+  const int img_base = bi * a.Ci * HWs;  // elements
+  const int tb = img_base + (UP2 ? 0 : h * W + w);
   const __amdgpu_buffer_rsrc_t rx = make_rsrc(a.x, a.x_bytes);
+  const uint32_t row_stride4 = (uint32_t)(BROWS * HWs) * 4u, row0_4 = (uint32_t)(kr0 * HWs) * 4u;
 
-  constexpr int AV = BK * BM / 4, AL = (AV + NT - 1) / NT;
-  float4 areg[AL];
+  constexpr int AV = BK * BM / 4, AL = (AV + NT - 1) / NT, AROWS = NT / (BM / 4);
+  // thread's first A element: row t/(BM/4), 4 columns at (t%(BM/4))*4; further loads are AROWS rows below
+  const float* pa0 = a.wp + (size_t)(t / (BM / 4)) * a.Mp + m0 + (t % (BM / 4)) * 4;
+  const size_t a_row_step = (size_t)AROWS * a.Mp;
+  f32x4 areg[AL];
   float breg[BL];
 
-  auto load_tile = [&](int kt) {
-    const int k0 = kt * BK;
+  auto load_tile = [&](int kt, int tap, int cib) {
+    const float* pk = pa0 + (size_t)kt * BK * a.Mp;
 #pragma unroll
-    for (int i = 0; i < AL; ++i) {
-      const int idx = t + i * NT;
-      if (AV % NT == 0 || idx < AV) {
-        const int kr = idx / (BM / 4), m = m0 + (idx % (BM / 4)) * 4;
-        areg[i] = (m < a.Mp) ? *reinterpret_cast<const float4*>(a.wp + (size_t)(k0 + kr) * a.Mp + m)
-                             : make_float4(0.f, 0.f, 0.f, 0.f);
-      }
-    }
+    for (int i = 0; i < AL; ++i)
+      if (AV % NT == 0 || t + i * NT < AV) areg[i] = *reinterpret_cast<const f32x4*>(pk + i * a_row_step);
+    const int dh = tap / KS - P, dw = tap - (tap / KS) * KS - P;  // scalar
+    const bool valid = (tapmask >> tap) & 1u;
+    int off;
+    if (UP2)
+      off = tb + ((h + dh) >> 1) * Ws + ((w + dw) >> 1) + cib * 16 * HWs;
+    else
+      off = tb + dh * W + dw + cib * 16 * HWs;
+    const uint32_t voff = valid ? (uint32_t)off * 4u : kOobBase;
 #pragma unroll
     for (int i = 0; i < BL; ++i) {
-      const int k = k0 + kr0 + i * BROWS;
-      const int ci = k / KK, tap = k - ci * KK;
-      const int dh = tap / KS - P, dw = tap % KS - P;
-      const bool valid = (k < a.K) && ((tapmask >> tap) & 1u);
-      int off;
-      if (UP2)
-        off = tbase + ci * HWs + ((h + dh) >> 1) * Ws + ((w + dw) >> 1);
-      else
-        off = tbase + ci * HW + dh * W + dw;
-      breg[i] = buf_load(rx, valid ? (uint32_t)off * 4u : kOOB);
+      uint32_t v = voff;
+      if (CI_TAIL) v = (cib * 16 + kr0 + i * BROWS < a.Ci) ? voff : kOobBase;  // padded channel rows (wave-uniform)
+      breg[i] = buf_load_s(rx, v, row0_4 + (uint32_t)i * row_stride4);
     }
   };
   auto store_tile = [&](int buf) {
 #pragma unroll
     for (int i = 0; i < AL; ++i) {
       const int idx = t + i * NT;
-      if (AV % NT == 0 || idx < AV) {
-        const int kr = idx / (BM / 4), m4 = (idx % (BM / 4)) * 4;
-        *reinterpret_cast<float4*>(&As[buf][kr * PA + m4]) = areg[i];
-      }
+      if (AV % NT == 0 || idx < AV)
+        *reinterpret_cast<f32x4*>(&As[buf][(idx / (BM / 4)) * PA + (idx % (BM / 4)) * 4]) = areg[i];
     }
 #pragma unroll
     for (int i = 0; i < BL; ++i) Bs[buf][(kr0 + i * BROWS) * PB + nl] = breg[i];
@@ -127,33 +169,17 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_fwd_kernel(ConvArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  auto compute = [&](int buf) {
-    const float* Ab = &As[buf][half * PA + wm * WTM + l31];
-    const float* Bb = &Bs[buf][half * PB + wn * WTN + l31];
-#pragma unroll
-    for (int kk = 0; kk < BK; kk += 2) {
-      float av[TM], bv[TN];
-#pragma unroll
-      for (int i = 0; i < TM; ++i) av[i] = Ab[kk * PA + i * 32];
-#pragma unroll
-      for (int j = 0; j < TN; ++j) bv[j] = Bb[kk * PB + j * 32];
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
-    }
-  };
-
   if (kt0 < kt1) {
-    load_tile(kt0);
+    int tap = kt0 / a.cpt, cib = kt0 - tap * a.cpt;
+    load_tile(kt0, tap, cib);
     store_tile(0);
     __syncthreads();
     int cur = 0;
     for (int kt = kt0; kt < kt1; ++kt) {
       const bool more = kt + 1 < kt1;
-      if (more) load_tile(kt + 1);
-      compute(cur);
+      if (++cib == a.cpt) cib = 0, ++tap;
+      if (more) load_tile(kt + 1, tap, cib);
+      mfma_tile<BK, PA, PB, TM, TN>(&As[cur][half * PA + wm * WTM + l31], &Bs[cur][half * PB + wn * WTN + l31], acc);
       if (more) store_tile(cur ^ 1);
       __syncthreads();
       cur ^= 1;
@@ -195,16 +221,16 @@ __global__ void splitk_reduce_fwd(const float* __restrict__ slab, const float* _
   }
 }
 
+// wp[(tap*Cip + c)][m]; for_dgrad swaps the channel roles and flips the taps
 __global__ void pack_weight_kernel(const float* __restrict__ w, float* __restrict__ wp, int Co, int Ci, int KK,
-                                   int for_dgrad, int K, int M, int Kp, int Mp) {
-  const size_t total = (size_t)Kp * Mp;
+                                   int for_dgrad, int C, int M, int Cip, int Mp) {
+  const size_t total = (size_t)KK * Cip * Mp;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
     const int k = (int)(i / Mp), m = (int)(i - (size_t)k * Mp);
+    const int tap = k / Cip, c = k - tap * Cip;
     float v = 0.f;
-    if (k < K && m < M) {
-      const int c = k / KK, tap = k - c * KK;
+    if (c < C && m < M)
       v = for_dgrad ? w[((size_t)c * Ci + m) * KK + (KK - 1 - tap)] : w[((size_t)m * Ci + c) * KK + tap];
-    }
     wp[i] = v;
   }
 }
@@ -213,21 +239,24 @@ __global__ void pack_weight_kernel(const float* __restrict__ w, float* __restric
 struct WgradArgs {
   const float* x;
   const float* dy;
-  float* out;  // slab base (or dw when splits == 1 and !accumulate)
+  float* out;
   int B, Ci, H, W, Co;
-  int Ntot, Ktot;
+  int Cip, Np, Ktot;  // Np = padded slab row length (nt*128)
   int mt, nt, tiles;
   int ktiles, ktiles_per_split, splits;
+  int w_shift, hw_shift;  // log2 when W / H*W are powers of two, else -1
   uint32_t x_bytes, dy_bytes;
   size_t slab_stride;
 };
 
-template <int KS, int BM, int BN, int WM, int WN, bool UP2>
+// CB = channels per 128-wide N tile (16/32/64/128); TPB = 128/CB taps per tile
+template <int KS, int BM, int CB, int WM, int WN, bool UP2>
 __global__ __launch_bounds__(WM* WN * 64) void conv_wgrad_kernel(WgradArgs a) {
-  constexpr int NT = WM * WN * 64, BK = 32, KK = KS * KS, P = KS / 2;
+  constexpr int NT = WM * WN * 64, BK = 32, BN = 128, KK = KS * KS, P = KS / 2, TPB = BN / CB;
   constexpr int WTM = BM / WM, WTN = BN / WN, TM = WTM / 32, TN = WTN / 32;
   constexpr int PA = BM + 1, PB = BN + 1;  // odd pitch: transposing ds_write_b32 is conflict free
   constexpr int RP = NT / 32, AL = BM / RP, BL = BN / RP;
+  static_assert(NT == 256 && RP == 8, "loader mapping assumes 256 threads");
   __shared__ float As[2][BK * PA];
   __shared__ float Bs[2][BK * PB];
 
@@ -237,35 +266,61 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_wgrad_kernel(WgradArgs a) {
   const int tile = q % a.tiles, sk = (q / a.tiles) * 8 + xcd;
   if (sk >= a.splits) return;
   const int tile_m = tile % a.mt, tile_n = tile / a.mt;
-  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int m0 = tile_m * BM;
+  int tap0, ci0;
+  if (CB == 128) {
+    const int per_tap = a.Cip / 128;
+    tap0 = tile_n / per_tap;
+    ci0 = (tile_n - tap0 * per_tap) * 128;
+  } else {
+    tap0 = tile_n * TPB;
+    ci0 = 0;
+  }
   const int kt0 = sk * a.ktiles_per_split;
   const int kt1 = min(a.ktiles, kt0 + a.ktiles_per_split);
   const int H = a.H, W = a.W, HW = H * W;
-  const int Hs = UP2 ? H / 2 : H, Ws = UP2 ? W / 2 : W;
+  const int Hs = UP2 ? H / 2 : H, Ws = UP2 ? W / 2 : W, HWs = Hs * Ws;
   const int kl = t & 31, r0 = t >> 5;
   const __amdgpu_buffer_rsrc_t rx = make_rsrc(a.x, a.x_bytes);
   const __amdgpu_buffer_rsrc_t rdy = make_rsrc(a.dy, a.dy_bytes);
+  const uint32_t a_stride4 = (uint32_t)(RP * HW) * 4u, b_unit4 = (uint32_t)HWs * 4u;
 
   float areg[AL], breg[BL];
   auto load_tile = [&](int kt) {
     const int k = kt * BK + kl;
     const bool kvalid = k < a.Ktot;
-    const int bi = k / HW, hw = k - bi * HW;
-    const int h = hw / W, w = hw - h * W;
+    int bi, hw, h, w;
+    if (a.hw_shift >= 0) {
+      bi = k >> a.hw_shift;
+      hw = k & (HW - 1);
+    } else {
+      bi = k / HW;
+      hw = k - bi * HW;
+    }
+    if (a.w_shift >= 0) {
+      h = hw >> a.w_shift;
+      w = hw & (W - 1);
+    } else {
+      h = hw / W;
+      w = hw - h * W;
+    }
+    // A rows m0+r0+8i of dY: rows past Co only feed accumulator rows that are never stored
+    const uint32_t va = kvalid ? (uint32_t)((bi * a.Co + m0 + r0) * HW + hw) * 4u : kOobBase;
 #pragma unroll
-    for (int i = 0; i < AL; ++i) {
-      const int m = m0 + r0 + i * RP;
-      const bool valid = kvalid && m < a.Co;
-      areg[i] = buf_load(rdy, valid ? (uint32_t)((bi * a.Co + m) * HW + hw) * 4u : kOOB);
+    for (int i = 0; i < AL; ++i) areg[i] = buf_load_s(rdy, va, (uint32_t)i * a_stride4);
+    uint32_t vb[TPB];
+#pragma unroll
+    for (int tl = 0; tl < TPB; ++tl) {
+      const int tap = tap0 + tl;
+      const int hh = h + tap / KS - P, ww = w + tap % KS - P;
+      const bool valid = kvalid && tap < KK && (unsigned)hh < (unsigned)H && (unsigned)ww < (unsigned)W;
+      const int hs = UP2 ? hh >> 1 : hh, wsrc = UP2 ? ww >> 1 : ww;
+      vb[tl] = valid ? (uint32_t)(((bi * a.Ci + ci0 + r0) * Hs + hs) * Ws + wsrc) * 4u : kOobBase;
     }
 #pragma unroll
     for (int i = 0; i < BL; ++i) {
-      const int nn = n0 + r0 + i * RP;
-      const int ci = nn / KK, tap = nn - ci * KK;
-      const int hh = h + tap / KS - P, ww = w + tap % KS - P;
-      const bool valid = kvalid && nn < a.Ntot && (unsigned)hh < (unsigned)H && (unsigned)ww < (unsigned)W;
-      const int hs = UP2 ? hh >> 1 : hh, wsrc = UP2 ? ww >> 1 : ww;
-      breg[i] = buf_load(rx, valid ? (uint32_t)(((bi * a.Ci + ci) * Hs + hs) * Ws + wsrc) * 4u : kOOB);
+      const int tl = (RP * i) / CB, cl = (RP * i) % CB;  // compile-time after unrolling
+      breg[i] = buf_load_s(rx, vb[tl], (uint32_t)cl * b_unit4);
     }
   };
   auto store_tile = [&](int buf) {
@@ -283,24 +338,6 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_wgrad_kernel(WgradArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  auto compute = [&](int buf) {
-    const float* Ab = &As[buf][half * PA + wm * WTM + l31];
-    const float* Bb = &Bs[buf][half * PB + wn * WTN + l31];
-#pragma unroll
-    for (int kk = 0; kk < BK; kk += 2) {
-      float av[TM], bv[TN];
-#pragma unroll
-      for (int i = 0; i < TM; ++i) av[i] = Ab[kk * PA + i * 32];
-#pragma unroll
-      for (int j = 0; j < TN; ++j) bv[j] = Bb[kk * PB + j * 32];
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
-    }
-  };
-
   if (kt0 < kt1) {
     load_tile(kt0);
     store_tile(0);
@@ -309,66 +346,98 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_wgrad_kernel(WgradArgs a) {
     for (int kt = kt0; kt < kt1; ++kt) {
       const bool more = kt + 1 < kt1;
       if (more) load_tile(kt + 1);
-      compute(cur);
+      mfma_tile<BK, PA, PB, TM, TN>(&As[cur][half * PA + wm * WTM + l31], &Bs[cur][half * PB + wn * WTN + l31], acc);
       if (more) store_tile(cur ^ 1);
       __syncthreads();
       cur ^= 1;
     }
   }
 
+  // slab[sk][m][tile_n*128 + nl], nl = tap_local*CB + channel_local
   float* out = a.out + (size_t)sk * a.slab_stride;
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
-    const int nn = n0 + wn * WTN + j * 32 + l31;
-    if (nn >= a.Ntot) continue;
+    const int nl = wn * WTN + j * 32 + l31;
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int m = m0 + wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-        if (m < a.Co) out[(size_t)m * a.Ntot + nn] = acc[i][j][r];
+        if (m < a.Co) out[(size_t)m * a.Np + tile_n * BN + nl] = acc[i][j][r];
       }
   }
 }
 
-__global__ void splitk_reduce_wgrad(const float* __restrict__ slab, float* __restrict__ dw, size_t total,
-                                    int splits, int accumulate) {
+// dw[co][ci][tap] (+)= sum_s slab[s][co][column(tap, ci)]
+__global__ void splitk_reduce_wgrad(const float* __restrict__ slab, float* __restrict__ dw, int Co, int Ci, int KK,
+                                    int Cip, int cb, int Np, size_t slab_stride, int splits, int accumulate) {
+  const size_t total = (size_t)Co * Ci * KK;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int tap = (int)(i % KK);
+    const size_t r = i / KK;
+    const int ci = (int)(r % Ci), co = (int)(r / Ci);
+    int col;
+    if (cb == 128) {
+      const int per_tap = Cip / 128;
+      col = (tap * per_tap + ci / 128) * 128 + (ci & 127);
+    } else {
+      const int tpb = 128 / cb;
+      col = (tap / tpb) * 128 + (tap % tpb) * cb + ci;
+    }
     float s = accumulate ? dw[i] : 0.f;
-    for (int k = 0; k < splits; ++k) s += slab[(size_t)k * total + i];
+    const float* p = slab + (size_t)co * Np + col;
+    for (int k = 0; k < splits; ++k) s += p[(size_t)k * slab_stride];
     dw[i] = s;
   }
 }
 
-// db[c] (+)= sum over (b, hw) of dy[b][c][hw]; one block per channel, fixed-order reduction
-__global__ __launch_bounds__(256) void bias_grad_kernel(const float* __restrict__ dy, float* __restrict__ db, int B,
-                                                        int C, int HW, int accumulate) {
+// db[c] (+)= sum over (b, hw) of dy[b][c][hw]: grid (C, splits) partials + fixed-order combine
+__global__ __launch_bounds__(256) void bias_grad_partial(const float* __restrict__ dy, double* __restrict__ part, int B,
+                                                         int C, int HW, int splits) {
   __shared__ double scratch[4];
-  const int c = blockIdx.x;
-  double s = 0.0;
+  const int c = blockIdx.x, s = blockIdx.y;
   const size_t total = (size_t)B * HW;
-  for (size_t i = threadIdx.x; i < total; i += blockDim.x) {
+  const size_t chunk = (total + splits - 1) / splits;
+  const size_t beg = (size_t)s * chunk, end = beg + chunk < total ? beg + chunk : total;
+  double acc = 0.0;
+  for (size_t i = beg + threadIdx.x; i < end; i += 256) {
     const size_t b = i / HW, hw = i - b * HW;
-    s += (double)dy[(b * C + c) * HW + hw];
+    acc += (double)dy[(b * C + c) * HW + hw];
   }
-  s = block_sum(s, scratch);
-  if (threadIdx.x == 0) db[c] = (accumulate ? db[c] : 0.f) + (float)s;
+  acc = block_sum(acc, scratch);
+  if (threadIdx.x == 0) part[(size_t)s * C + c] = acc;
+}
+__global__ void bias_grad_combine(const double* __restrict__ part, float* __restrict__ db, int C, int splits,
+                                  int accumulate) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s = 0.0;
+  for (int k = 0; k < splits; ++k) s += part[(size_t)k * C + c];
+  db[c] = (accumulate ? db[c] : 0.f) + (float)s;
 }
 
 // ------------------------------------------------------------------------------ host side
+static inline int pad16(int c) { return (c + 15) & ~15; }
+static inline int log2_exact(int v) {
+  if (v <= 0 || (v & (v - 1))) return -1;
+  int s = 0;
+  while ((1 << s) < v) ++s;
+  return s;
+}
+
 struct FwdPlan {
-  int bm, bn, mt, nt, ktiles, splits, kps;
+  int bm, bn, mt, nt, cip, ktiles, splits, kps;
 };
 
 static FwdPlan plan_fwd(int B, int Ci, int H, int W, int Co, int KS) {
   FwdPlan p;
-  const int K = Ci * KS * KS;
   const long long N = (long long)B * H * W;
-  p.bm = Co <= 32 ? 32 : (Co <= 64 ? 64 : 128);
+  p.bm = tile_rows_for(Co);
   p.bn = p.bm == 128 ? 128 : 256;
   p.mt = cdiv(Co, p.bm);
   p.nt = (int)((N + p.bn - 1) / p.bn);
-  p.ktiles = cdiv(K, 16);
+  p.cip = pad16(Ci);
+  p.ktiles = KS * KS * (p.cip / 16);
   const int tiles = p.mt * p.nt;
   int splits = 1;
   if (tiles < 192 && p.ktiles >= 8) {
@@ -383,16 +452,17 @@ static FwdPlan plan_fwd(int B, int Ci, int H, int W, int Co, int KS) {
 }
 
 struct WgPlan {
-  int bm, mt, nt, tiles, ktiles, splits, kps;
+  int bm, cb, cip, mt, nt, tiles, ktiles, splits, kps;
 };
 
 static WgPlan plan_wgrad(int B, int Ci, int H, int W, int Co, int KS) {
   WgPlan p;
-  const int Ntot = Ci * KS * KS;
   const long long Ktot = (long long)B * H * W;
-  p.bm = Co <= 32 ? 32 : (Co <= 64 ? 64 : 128);
+  p.bm = tile_rows_for(Co);
+  p.cb = Ci <= 16 ? 16 : (Ci <= 32 ? 32 : (Ci <= 64 ? 64 : 128));
+  p.cip = p.cb < 128 ? p.cb : (Ci + 127) / 128 * 128;
   p.mt = cdiv(Co, p.bm);
-  p.nt = cdiv(Ntot, 128);
+  p.nt = p.cb == 128 ? KS * KS * (p.cip / 128) : cdiv(KS * KS, 128 / p.cb);
   p.tiles = p.mt * p.nt;
   p.ktiles = (int)((Ktot + 31) / 32);
   int splits = cdiv(768, p.tiles);
@@ -406,11 +476,16 @@ static WgPlan plan_wgrad(int B, int Ci, int H, int W, int Co, int KS) {
 
 template <int KS, int BM, int BN, int WM, int WN>
 static void launch_fwd_cfg(const ConvArgs& a, int splits, int up2, hipStream_t st) {
-  dim3 grid(cdiv(a.nt, 8) * 8 * a.mt, splits);
-  if (up2)
-    hipLaunchKernelGGL((conv_fwd_kernel<KS, BM, BN, WM, WN, true>), grid, dim3(WM * WN * 64), 0, st, a);
+  dim3 grid(cdiv(a.nt, 8) * 8 * a.mt, splits), block(WM * WN * 64);
+  const bool tail = (a.Ci & 15) != 0;
+  if (up2 && tail)
+    hipLaunchKernelGGL((conv_fwd_kernel<KS, BM, BN, WM, WN, true, true>), grid, block, 0, st, a);
+  else if (up2)
+    hipLaunchKernelGGL((conv_fwd_kernel<KS, BM, BN, WM, WN, true, false>), grid, block, 0, st, a);
+  else if (tail)
+    hipLaunchKernelGGL((conv_fwd_kernel<KS, BM, BN, WM, WN, false, true>), grid, block, 0, st, a);
   else
-    hipLaunchKernelGGL((conv_fwd_kernel<KS, BM, BN, WM, WN, false>), grid, dim3(WM * WN * 64), 0, st, a);
+    hipLaunchKernelGGL((conv_fwd_kernel<KS, BM, BN, WM, WN, false, false>), grid, block, 0, st, a);
 }
 
 template <int KS>
@@ -423,31 +498,51 @@ static void launch_fwd(const ConvArgs& a, int bm, int splits, int up2, hipStream
     launch_fwd_cfg<KS, 128, 128, 2, 2>(a, splits, up2, st);
 }
 
-template <int KS, bool UP2>
-static void launch_wgrad_up(const WgradArgs& a, int bm, hipStream_t st) {
+template <int KS, int CB, bool UP2>
+static void launch_wgrad_bm(const WgradArgs& a, int bm, hipStream_t st) {
   dim3 grid(cdiv(a.splits, 8) * 8 * a.tiles);
   if (bm == 32)
-    hipLaunchKernelGGL((conv_wgrad_kernel<KS, 32, 128, 1, 4, UP2>), grid, dim3(256), 0, st, a);
+    hipLaunchKernelGGL((conv_wgrad_kernel<KS, 32, CB, 1, 4, UP2>), grid, dim3(256), 0, st, a);
   else if (bm == 64)
-    hipLaunchKernelGGL((conv_wgrad_kernel<KS, 64, 128, 1, 4, UP2>), grid, dim3(256), 0, st, a);
+    hipLaunchKernelGGL((conv_wgrad_kernel<KS, 64, CB, 1, 4, UP2>), grid, dim3(256), 0, st, a);
   else
-    hipLaunchKernelGGL((conv_wgrad_kernel<KS, 128, 128, 2, 2, UP2>), grid, dim3(256), 0, st, a);
+    hipLaunchKernelGGL((conv_wgrad_kernel<KS, 128, CB, 2, 2, UP2>), grid, dim3(256), 0, st, a);
+}
+template <int KS, bool UP2>
+static void launch_wgrad_cb(const WgradArgs& a, int bm, int cb, hipStream_t st) {
+  if (cb == 16)
+    launch_wgrad_bm<KS, 16, UP2>(a, bm, st);
+  else if (cb == 32)
+    launch_wgrad_bm<KS, 32, UP2>(a, bm, st);
+  else if (cb == 64)
+    launch_wgrad_bm<KS, 64, UP2>(a, bm, st);
+  else
+    launch_wgrad_bm<KS, 128, UP2>(a, bm, st);
 }
 template <int KS>
-static void launch_wgrad(const WgradArgs& a, int bm, int up2, hipStream_t st) {
+static void launch_wgrad(const WgradArgs& a, int bm, int cb, int up2, hipStream_t st) {
   if (up2)
-    launch_wgrad_up<KS, true>(a, bm, st);
+    launch_wgrad_cb<KS, true>(a, bm, cb, st);
   else
-    launch_wgrad_up<KS, false>(a, bm, st);
+    launch_wgrad_cb<KS, false>(a, bm, cb, st);
 }
 
 static int check_dims(const char* name, int B, int Ci, int H, int W, int Co, int KS) {
   if (!(KS == 1 || KS == 3 || KS == 5)) return fail("%s: kernel size must be 1, 3 or 5 (got %lld)", name, KS);
   if (B <= 0 || Ci <= 0 || H <= 0 || W <= 0 || Co <= 0) return fail("%s: empty or negative dimension", name);
-  const long long in_elems = (long long)B * Ci * H * W, out_elems = (long long)B * Co * H * W;
-  if (in_elems >= (1LL << 30) || out_elems >= (1LL << 30))
-    return fail("%s: tensor too large for 32-bit buffer offsets (%lld / %lld elements)", name, in_elems, out_elems);
+  const long long in_elems = (long long)B * pad16(Ci) * H * W, out_elems = (long long)B * Co * H * W;
+  if (in_elems >= (1LL << 29) || out_elems >= (1LL << 29))
+    return fail("%s: tensor too large for 31-bit buffer offsets (%lld / %lld elements)", name, in_elems, out_elems);
   return 0;
+}
+
+constexpr int kBiasSplitsMax = 256;
+static inline int bias_splits(int B, int C, int HW) {
+  int s = cdiv(1024, C);
+  const size_t maxs = cdivz((size_t)B * HW, 2048);
+  if ((size_t)s > maxs) s = (int)maxs;
+  if (s > kBiasSplitsMax) s = kBiasSplitsMax;
+  return s < 1 ? 1 : s;
 }
 
 }  // namespace itcv
@@ -457,18 +552,19 @@ using namespace itcv;
 extern "C" {
 
 size_t itcv_conv2d_packed_weight_elems(int Co, int Ci, int KS, int for_dgrad) {
-  const int M = for_dgrad ? Ci : Co, K = (for_dgrad ? Co : Ci) * KS * KS;
-  return align_up(K, 16) * align_up(M, 32);
+  const int M = for_dgrad ? Ci : Co, C = for_dgrad ? Co : Ci;
+  const int bm = tile_rows_for(M);
+  return (size_t)KS * KS * pad16(C) * (cdiv(M, bm) * bm);
 }
 
 int itcv_conv2d_pack_weight(const float* w, float* wp, int Co, int Ci, int KS, int for_dgrad, void* stream) {
   ITCV_REQUIRE(w && wp && Co > 0 && Ci > 0 && (KS == 1 || KS == 3 || KS == 5), "itcv_conv2d_pack_weight");
-  const int M = for_dgrad ? Ci : Co, K = (for_dgrad ? Co : Ci) * KS * KS;
-  const int Kp = (int)align_up(K, 16), Mp = (int)align_up(M, 32);
-  const size_t total = (size_t)Kp * Mp;
+  const int M = for_dgrad ? Ci : Co, C = for_dgrad ? Co : Ci;
+  const int bm = tile_rows_for(M), Mp = cdiv(M, bm) * bm, Cip = pad16(C);
+  const size_t total = (size_t)KS * KS * Cip * Mp;
   const int blocks = (int)(cdivz(total, 256) < 4096 ? cdivz(total, 256) : 4096);
   hipLaunchKernelGGL(pack_weight_kernel, dim3(blocks), dim3(256), 0, S(stream), w, wp, Co, Ci, KS * KS, for_dgrad,
-                     K, M, Kp, Mp);
+                     C, M, Cip, Mp);
   ITCV_CHECK_LAUNCH("itcv_conv2d_pack_weight");
   return 0;
 }
@@ -495,10 +591,10 @@ int itcv_conv2d_fwd(const float* x, const float* wp, const float* bias, float* y
   a.bias = p.splits > 1 ? nullptr : bias;
   a.y = p.splits > 1 ? static_cast<float*>(ws) : y;
   a.B = B, a.Ci = Ci, a.H = H, a.W = W, a.Co = Co;
-  a.Mp = (int)align_up(Co, 32);
-  a.K = Ci * KS * KS;
+  a.Cip = p.cip;
+  a.Mp = p.mt * p.bm;
   a.N = B * H * W;
-  a.mt = p.mt, a.nt = p.nt, a.ktiles = p.ktiles, a.ktiles_per_split = p.kps;
+  a.mt = p.mt, a.nt = p.nt, a.ktiles = p.ktiles, a.ktiles_per_split = p.kps, a.cpt = p.cip / 16;
   a.x_bytes = (uint32_t)((size_t)B * Ci * (up2 ? (H / 2) * (W / 2) : H * W) * sizeof(float));
   a.slab_stride = p.splits > 1 ? out_elems : 0;
   hipStream_t st = S(stream);
@@ -521,7 +617,7 @@ int itcv_conv2d_fwd(const float* x, const float* wp, const float* bias, float* y
 size_t itcv_conv2d_wgrad_workspace(int B, int Ci, int H, int W, int Co, int KS) {
   if (B <= 0 || Ci <= 0 || H <= 0 || W <= 0 || Co <= 0) return 0;
   const WgPlan p = plan_wgrad(B, Ci, H, W, Co, KS);
-  return (size_t)p.splits * Co * Ci * KS * KS * sizeof(float);
+  return (size_t)p.splits * Co * p.nt * 128 * sizeof(float);
 }
 
 int itcv_conv2d_wgrad(const float* x, const float* dy, float* dw, int B, int Ci, int H, int W, int Co, int KS,
@@ -530,36 +626,36 @@ int itcv_conv2d_wgrad(const float* x, const float* dy, float* dw, int B, int Ci,
   ITCV_REQUIRE(x && dy && dw, "itcv_conv2d_wgrad");
   if (up2) ITCV_REQUIRE(H % 2 == 0 && W % 2 == 0, "itcv_conv2d_wgrad(up2)");
   const WgPlan p = plan_wgrad(B, Ci, H, W, Co, KS);
-  const size_t dw_elems = (size_t)Co * Ci * KS * KS;
-  const bool direct = p.splits == 1 && !accumulate;
-  if (!direct && (!ws || ws_bytes < (size_t)p.splits * dw_elems * sizeof(float)))
+  const size_t slab = (size_t)Co * p.nt * 128;
+  if (!ws || ws_bytes < (size_t)p.splits * slab * sizeof(float))
     return fail("%s: workspace too small (need %lld bytes)", "itcv_conv2d_wgrad",
-                (long long)((size_t)p.splits * dw_elems * sizeof(float)));
+                (long long)((size_t)p.splits * slab * sizeof(float)));
   WgradArgs a;
   a.x = x, a.dy = dy;
-  a.out = direct ? dw : static_cast<float*>(ws);
+  a.out = static_cast<float*>(ws);
   a.B = B, a.Ci = Ci, a.H = H, a.W = W, a.Co = Co;
-  a.Ntot = Ci * KS * KS;
+  a.Cip = p.cip;
+  a.Np = p.nt * 128;
   a.Ktot = B * H * W;
   a.mt = p.mt, a.nt = p.nt, a.tiles = p.tiles;
   a.ktiles = p.ktiles, a.ktiles_per_split = p.kps, a.splits = p.splits;
+  a.w_shift = log2_exact(W), a.hw_shift = log2_exact(H * W);
   a.x_bytes = (uint32_t)((size_t)B * Ci * (up2 ? (H / 2) * (W / 2) : H * W) * sizeof(float));
   a.dy_bytes = (uint32_t)((size_t)B * Co * H * W * sizeof(float));
-  a.slab_stride = dw_elems;
+  a.slab_stride = slab;
   hipStream_t st = S(stream);
   if (KS == 1)
-    launch_wgrad<1>(a, p.bm, up2, st);
+    launch_wgrad<1>(a, p.bm, p.cb, up2, st);
   else if (KS == 3)
-    launch_wgrad<3>(a, p.bm, up2, st);
+    launch_wgrad<3>(a, p.bm, p.cb, up2, st);
   else
-    launch_wgrad<5>(a, p.bm, up2, st);
+    launch_wgrad<5>(a, p.bm, p.cb, up2, st);
   ITCV_CHECK_LAUNCH("itcv_conv2d_wgrad");
-  if (!direct) {
-    const int blocks = (int)(cdivz(dw_elems, 256) < 2048 ? cdivz(dw_elems, 256) : 2048);
-    hipLaunchKernelGGL(splitk_reduce_wgrad, dim3(blocks), dim3(256), 0, st, static_cast<const float*>(ws), dw,
-                       dw_elems, p.splits, accumulate);
-    ITCV_CHECK_LAUNCH("itcv_conv2d_wgrad(reduce)");
-  }
+  const size_t dw_elems = (size_t)Co * Ci * KS * KS;
+  const int blocks = (int)(cdivz(dw_elems, 256) < 2048 ? cdivz(dw_elems, 256) : 2048);
+  hipLaunchKernelGGL(splitk_reduce_wgrad, dim3(blocks), dim3(256), 0, st, static_cast<const float*>(ws), dw, Co, Ci,
+                     KS * KS, p.cip, p.cb, a.Np, slab, p.splits, accumulate);
+  ITCV_CHECK_LAUNCH("itcv_conv2d_wgrad(reduce)");
   return 0;
 }
 
@@ -576,10 +672,20 @@ int itcv_conv2d_wgrad_variant(int B, int Ci, int H, int W, int Co, int KS, int u
   return p.bm | (KS << 8) | ((up2 ? 1 : 0) << 16) | (p.splits << 20);
 }
 
-int itcv_bias_grad(const float* dy, float* db, int B, int C, int HW, int accumulate, void* stream) {
+size_t itcv_bias_grad_workspace(int B, int C, int HW) {
+  return B > 0 && C > 0 && HW > 0 ? (size_t)bias_splits(B, C, HW) * C * sizeof(double) : 0;
+}
+
+int itcv_bias_grad(const float* dy, float* db, int B, int C, int HW, int accumulate, void* ws, size_t ws_bytes,
+                   void* stream) {
   ITCV_REQUIRE(dy && db && B > 0 && C > 0 && HW > 0, "itcv_bias_grad");
-  hipLaunchKernelGGL(bias_grad_kernel, dim3(C), dim3(256), 0, S(stream), dy, db, B, C, HW, accumulate);
+  const int splits = bias_splits(B, C, HW);
+  ITCV_REQUIRE(ws && ws_bytes >= (size_t)splits * C * sizeof(double), "itcv_bias_grad(workspace)");
+  double* part = static_cast<double*>(ws);
+  hipLaunchKernelGGL(bias_grad_partial, dim3(C, splits), dim3(256), 0, S(stream), dy, part, B, C, HW, splits);
   ITCV_CHECK_LAUNCH("itcv_bias_grad");
+  hipLaunchKernelGGL(bias_grad_combine, dim3(cdiv(C, 256)), dim3(256), 0, S(stream), part, db, C, splits, accumulate);
+  ITCV_CHECK_LAUNCH("itcv_bias_grad(combine)");
   return 0;
 }
 

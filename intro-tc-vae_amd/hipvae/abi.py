@@ -35,7 +35,8 @@ SIGNATURES = {
     "itcv_conv2d_wgrad": (i32, [p, p, p, i32, i32, i32, i32, i32, i32, i32, i32, p, sz, p]),
     "itcv_conv2d_fwd_variant": (i32, [i32] * 7),
     "itcv_conv2d_wgrad_variant": (i32, [i32] * 7),
-    "itcv_bias_grad": (i32, [p, p, i32, i32, i32, i32, p]),
+    "itcv_bias_grad_workspace": (sz, [i32, i32, i32]),
+    "itcv_bias_grad": (i32, [p, p, i32, i32, i32, i32, p, sz, p]),
     "itcv_bn_workspace": (sz, [i32, i32, i32]),
     "itcv_bn_moments": (i32, [p, p, i32, i32, i32, p, sz, p]),
     "itcv_bn_finalize": (i32, [p, f64, f32, f32, p, p, p, p, p, i32, p]),

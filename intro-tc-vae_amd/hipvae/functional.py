@@ -98,7 +98,9 @@ def conv_wgrad_raw(x, dy, B, Ci, H, W, Co, KS, up2, out=None, accumulate=False):
 
 def bias_grad_raw(dy, B, C, HW):
     db = torch.empty((C,), dtype=F32, device=dy.device)
-    call("itcv_bias_grad", ptr(dy), ptr(db), B, C, HW, 0, stream())
+    nws = lib.itcv_bias_grad_workspace(B, C, HW)
+    ws = _ws(nws, dy.device)
+    call("itcv_bias_grad", ptr(dy), ptr(db), B, C, HW, 0, ptr(ws), nws, stream())
     return db
 
 
