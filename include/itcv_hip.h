@@ -74,6 +74,10 @@ size_t itcv_bn_workspace(int B, int C, int HW);
 /* sums[0..C) = sum x, sums[C..2C) = sum x^2 over (b,hw); deterministic two-stage reduction */
 int itcv_bn_moments(const float* x, double* sums, int B, int C, int HW, void* ws, size_t ws_bytes,
                     void* stream);
+/* single-rank fast path: moments + finalize of this rank's own batch in two launches */
+int itcv_bn_train_stats(const float* x, int B, int C, int HW, float eps, float momentum, float* running_mean,
+                        float* running_var, int64_t* num_batches_tracked, float* mean, float* rstd, void* ws,
+                        size_t ws_bytes, void* stream);
 /* mean/rstd from the moments of `count` samples; updates running_mean/var (momentum, unbiased
  * variance) and num_batches_tracked when those pointers are non-NULL. */
 int itcv_bn_finalize(const double* sums, double count, float eps, float momentum, float* running_mean,
@@ -90,11 +94,13 @@ int itcv_bn_act_fwd(const float* x, const float* mean, const float* rstd, const 
                     float slope, int pool, void* stream);
 /* backward, stage 1: dsums[0..C) = sum g, dsums[C..2C) = sum g*xhat where
  * g = unpool(dy) * lrelu'(bn_out (+skip)); `up2`!=0 means dy is the gradient of the x2-upsampled
- * output (dy [B][C][2H][2W], summed 2x2 on the fly: adjoint of models.py:284-286). */
+ * output (dy [B][C][2H][2W], summed 2x2 on the fly: adjoint of models.py:284-286).  When non-NULL,
+ * dgamma (+)= dsums[C+c] and dbeta (+)= dsums[c] are written by the same launch (the rank's own
+ * sums are the parameter gradients, also under Sync-BN). */
 int itcv_bn_act_bwd_reduce(const float* x, const float* dy, const float* mean, const float* rstd,
                            const float* gamma, const float* beta, const float* skip, double* dsums,
-                           int B, int C, int H, int W, float slope, int pool, int up2, void* ws,
-                           size_t ws_bytes, void* stream);
+                           float* dgamma, float* dbeta, int accumulate, int B, int C, int H, int W,
+                           float slope, int pool, int up2, void* ws, size_t ws_bytes, void* stream);
 /* backward, stage 2: dx = gamma*rstd*(g - dsums[c]/count - xhat*dsums[C+c]/count);
  * dgamma (+)= local_dsums[C+c], dbeta (+)= local_dsums[c] when non-NULL (local_dsums = the rank's
  * own sums; dsums may have been all-reduced for Sync-BN); dskip = g when non-NULL. */

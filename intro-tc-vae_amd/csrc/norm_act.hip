@@ -69,6 +69,46 @@ __global__ void bn_finalize_kernel(const double* __restrict__ sums, double count
   }
 }
 
+// single-rank fast path: fold the partial sums and finalise in one launch
+__global__ void bn_combine_finalize_kernel(const double* __restrict__ part, int splits, double count, float eps,
+                                           float momentum, float* running_mean, float* running_var, int64_t* nbt,
+                                           float* mean, float* rstd, int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c == 0 && nbt) nbt[0] += 1;
+  if (c >= C) return;
+  double s1 = 0.0, s2 = 0.0;
+  for (int k = 0; k < splits; ++k) {
+    s1 += part[((size_t)k * 2 + 0) * C + c];
+    s2 += part[((size_t)k * 2 + 1) * C + c];
+  }
+  const double m = s1 / count;
+  double var = s2 / count - m * m;
+  if (var < 0.0) var = 0.0;
+  mean[c] = (float)m;
+  rstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+  if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)m;
+  if (running_var) {
+    const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+    running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+  }
+}
+
+// backward: fold the partial sums into dsums and (optionally) the parameter gradients
+__global__ void bn_combine_param_kernel(const double* __restrict__ part, double* __restrict__ dsums, int C,
+                                        int splits, float* dgamma, float* dbeta, int accumulate) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s1 = 0.0, s2 = 0.0;
+  for (int k = 0; k < splits; ++k) {
+    s1 += part[((size_t)k * 2 + 0) * C + c];
+    s2 += part[((size_t)k * 2 + 1) * C + c];
+  }
+  dsums[c] = s1;
+  dsums[C + c] = s2;
+  if (dbeta) dbeta[c] = (accumulate ? dbeta[c] : 0.f) + (float)s1;
+  if (dgamma) dgamma[c] = (accumulate ? dgamma[c] : 0.f) + (float)s2;
+}
+
 __global__ void bn_eval_stats_kernel(const float* rm, const float* rv, float eps, float* mean, float* rstd, int C) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
@@ -308,6 +348,21 @@ int itcv_bn_moments(const float* x, double* sums, int B, int C, int HW, void* ws
   return 0;
 }
 
+int itcv_bn_train_stats(const float* x, int B, int C, int HW, float eps, float momentum, float* running_mean,
+                        float* running_var, int64_t* num_batches_tracked, float* mean, float* rstd, void* ws,
+                        size_t ws_bytes, void* stream) {
+  ITCV_REQUIRE(x && mean && rstd && B > 0 && C > 0 && HW > 0, "itcv_bn_train_stats");
+  const int splits = bn_splits(B, C, HW);
+  ITCV_REQUIRE(ws && ws_bytes >= (size_t)splits * 2 * C * sizeof(double), "itcv_bn_train_stats(workspace)");
+  double* part = static_cast<double*>(ws);
+  hipLaunchKernelGGL(bn_moments_partial, dim3(C, splits), dim3(kRedThreads), 0, S(stream), x, part, B, C, HW, splits);
+  ITCV_CHECK_LAUNCH("itcv_bn_train_stats");
+  hipLaunchKernelGGL(bn_combine_finalize_kernel, dim3(cdiv(C, 256)), dim3(256), 0, S(stream), part, splits,
+                     (double)B * HW, eps, momentum, running_mean, running_var, num_batches_tracked, mean, rstd, C);
+  ITCV_CHECK_LAUNCH("itcv_bn_train_stats(finalize)");
+  return 0;
+}
+
 int itcv_bn_finalize(const double* sums, double count, float eps, float momentum, float* running_mean,
                      float* running_var, int64_t* num_batches_tracked, float* mean, float* rstd, int C,
                      void* stream) {
@@ -346,8 +401,9 @@ int itcv_bn_act_fwd(const float* x, const float* mean, const float* rstd, const 
 }
 
 int itcv_bn_act_bwd_reduce(const float* x, const float* dy, const float* mean, const float* rstd, const float* gamma,
-                           const float* beta, const float* skip, double* dsums, int B, int C, int H, int W,
-                           float slope, int pool, int up2, void* ws, size_t ws_bytes, void* stream) {
+                           const float* beta, const float* skip, double* dsums, float* dgamma, float* dbeta,
+                           int accumulate, int B, int C, int H, int W, float slope, int pool, int up2, void* ws,
+                           size_t ws_bytes, void* stream) {
   ITCV_REQUIRE(x && dy && mean && rstd && gamma && beta && dsums && B > 0 && C > 0, "itcv_bn_act_bwd_reduce");
   ITCV_REQUIRE(!(pool && up2), "itcv_bn_act_bwd_reduce(pool and up2 are exclusive)");
   if (pool) ITCV_REQUIRE(H % 2 == 0 && W % 2 == 0, "itcv_bn_act_bwd_reduce(pool)");
@@ -365,7 +421,8 @@ int itcv_bn_act_bwd_reduce(const float* x, const float* dy, const float* mean, c
     hipLaunchKernelGGL(bn_bwd_partial<0>, grid, dim3(kRedThreads), 0, S(stream), x, dy, mean, rstd, gamma, beta, skip,
                        part, B, C, H, W, slope, splits);
   ITCV_CHECK_LAUNCH("itcv_bn_act_bwd_reduce");
-  hipLaunchKernelGGL(combine_partials, dim3(cdiv(2 * C, 256)), dim3(256), 0, S(stream), part, dsums, 2 * C, splits);
+  hipLaunchKernelGGL(bn_combine_param_kernel, dim3(cdiv(C, 256)), dim3(256), 0, S(stream), part, dsums, C, splits,
+                     dgamma, dbeta, accumulate);
   ITCV_CHECK_LAUNCH("itcv_bn_act_bwd_reduce(combine)");
   return 0;
 }

@@ -61,7 +61,10 @@ class _AllGatherRows(Function):
         ctx.group = group
         world = dist.get_world_size(group)
         out = torch.empty((world * x.shape[0],) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
-        dist.all_gather_into_tensor(out, x.contiguous(), group=group)
+        if dist.get_backend(group) == "gloo":
+            dist.all_gather(list(out.chunk(world, dim=0)), x.contiguous(), group=group)
+        else:
+            dist.all_gather_into_tensor(out, x.contiguous(), group=group)
         return out
 
     @staticmethod

@@ -9,6 +9,7 @@ themselves are untouched, so optimizers and state_dicts that reference them stay
 import torch
 
 from .abi import call, lib, ptr, stream
+from .functional import bump_weight_epoch
 
 F32 = torch.float32
 
@@ -61,6 +62,7 @@ class FlatGroup:
         self.step += 1
         call("itcv_adam_step", ptr(self.flat_p), ptr(self.flat_g), ptr(self.exp_avg), ptr(self.exp_avg_sq),
              self.numel, float(lr), float(betas[0]), float(betas[1]), float(eps), self.step, stream())
+        bump_weight_epoch()          # parameters changed behind torch's back: drop packed-weight caches
 
 
 def clip_grad_norm(groups, clip):

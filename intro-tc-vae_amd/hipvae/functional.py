@@ -7,6 +7,9 @@ The optional ``group`` arguments are torch.distributed process groups: they turn
 into Sync-BN (all-reduce of the fp64 channel moments over RCCL) for data-parallel parity
 with the full-batch reference.
 """
+import contextlib
+import weakref
+
 import torch
 import torch.distributed as dist
 from torch.autograd import Function
@@ -28,7 +31,55 @@ def _f32c(t):
     return t if t.is_contiguous() else t.contiguous()
 
 
+# ------------------------------------------------------------------ gradient accumulation mode
+_DIRECT = [False]
+
+
+@contextlib.contextmanager
+def direct_grad_accumulation():
+    """Inside this block the backward kernels add parameter gradients straight into an existing,
+    contiguous ``param.grad`` (the solvers' flat gradient buffers) and hand autograd ``None``,
+    instead of returning fresh tensors for autograd to add (saves one elementwise pass and one
+    launch per parameter per network pass)."""
+    prev, _DIRECT[0] = _DIRECT[0], True
+    try:
+        yield
+    finally:
+        _DIRECT[0] = prev
+
+
+def _grad_target(param):
+    g = param.grad if _DIRECT[0] else None
+    return g if (g is not None and g.is_contiguous() and g.dtype == F32) else None
+
+
 # ------------------------------------------------------------------ convolution / linear
+_WEIGHT_EPOCH = [0]
+_PACK_CACHE = {}
+
+
+def bump_weight_epoch():
+    """Call after parameters were modified through raw pointers (fused Adam): invalidates the
+    packed-weight cache (torch's own in-place ops are tracked through ``tensor._version``)."""
+    _WEIGHT_EPOCH[0] += 1
+
+
+def packed_weight(weight, w4, for_dgrad):
+    """Packed operand of ``weight`` (viewed as ``w4`` [Co,Ci,KS,KS]), cached until the weight changes:
+    the frozen half of the model is packed once per phase instead of once per network pass."""
+    key = (weight.data_ptr(), weight._version, _WEIGHT_EPOCH[0])
+    ent = _PACK_CACHE.get(id(weight))
+    if ent is None:
+        ent = _PACK_CACHE[id(weight)] = [key, {}]
+        weakref.finalize(weight, _PACK_CACHE.pop, id(weight), None)
+    elif ent[0] != key:
+        ent[0], ent[1] = key, {}
+    wp = ent[1].get(for_dgrad)
+    if wp is None:
+        wp = ent[1][for_dgrad] = pack_weight(w4, for_dgrad)
+    return wp
+
+
 def pack_weight(w4, for_dgrad):
     """w4 [Co,Ci,KS,KS] -> packed K-major operand (see include/itcv_hip.h)."""
     co, ci, ks = w4.shape[0], w4.shape[1], w4.shape[2]
@@ -96,12 +147,13 @@ def conv_wgrad_raw(x, dy, B, Ci, H, W, Co, KS, up2, out=None, accumulate=False):
                      2.0 * B * H * W * Co * Ci * KS * KS, launch)
 
 
-def bias_grad_raw(dy, B, C, HW):
-    db = torch.empty((C,), dtype=F32, device=dy.device)
+def bias_grad_raw(dy, B, C, HW, target=None):
+    """db = sum_{b,hw} dy; with ``target`` the sum is added into it and None is returned."""
+    db = target if target is not None else torch.empty((C,), dtype=F32, device=dy.device)
     nws = lib.itcv_bias_grad_workspace(B, C, HW)
     ws = _ws(nws, dy.device)
-    call("itcv_bias_grad", ptr(dy), ptr(db), B, C, HW, 0, ptr(ws), nws, stream())
-    return db
+    call("itcv_bias_grad", ptr(dy), ptr(db), B, C, HW, int(target is not None), ptr(ws), nws, stream())
+    return None if target is not None else db
 
 
 class Conv2dFn(Function):
@@ -114,28 +166,33 @@ class Conv2dFn(Function):
         B, Ci, Hs, Ws = x.shape
         Co, KS = weight.shape[0], weight.shape[2]
         H, W = (Hs * 2, Ws * 2) if up2 else (Hs, Ws)
-        y = conv_fwd_raw(x, pack_weight(weight, 0), None if bias is None else _f32c(bias), B, Ci, H, W, Co, KS, up2)
-        ctx.save_for_backward(x, weight)
+        y = conv_fwd_raw(x, packed_weight(weight, weight, 0), None if bias is None else _f32c(bias), B, Ci, H, W, Co,
+                         KS, up2)
+        ctx.save_for_backward(x, weight, bias)
         ctx.cfg = (B, Ci, H, W, Co, KS, up2, bias is not None)
         return y
 
     @staticmethod
     @once_differentiable
     def backward(ctx, dy):
-        x, weight = ctx.saved_tensors
+        x, weight, bias = ctx.saved_tensors
         B, Ci, H, W, Co, KS, up2, has_bias = ctx.cfg
         dy = _f32c(dy)
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            dx = conv_fwd_raw(dy, pack_weight(weight, 1), None, B, Co, H, W, Ci, KS, False)
+            dx = conv_fwd_raw(dy, packed_weight(weight, weight, 1), None, B, Co, H, W, Ci, KS, False)
             if up2:
                 lo = torch.empty((B, Ci, H // 2, W // 2), dtype=F32, device=dy.device)
                 call("itcv_upsample2_bwd", ptr(dx), ptr(lo), B * Ci, H // 2, W // 2, stream())
                 dx = lo
         if ctx.needs_input_grad[1]:
-            dw = conv_wgrad_raw(x, dy, B, Ci, H, W, Co, KS, up2)
+            tgt = _grad_target(weight)
+            if tgt is not None:
+                conv_wgrad_raw(x, dy, B, Ci, H, W, Co, KS, up2, out=tgt, accumulate=True)
+            else:
+                dw = conv_wgrad_raw(x, dy, B, Ci, H, W, Co, KS, up2)
         if has_bias and ctx.needs_input_grad[2]:
-            db = bias_grad_raw(dy, B, Co, H * W)
+            db = bias_grad_raw(dy, B, Co, H * W, _grad_target(bias))
         return dx, dw, db, None
 
 
@@ -148,24 +205,30 @@ class LinearFn(Function):
         B, Ci = x.shape
         Co = weight.shape[0]
         w4 = weight.view(Co, Ci, 1, 1)
-        y = conv_fwd_raw(x, pack_weight(w4, 0), None if bias is None else _f32c(bias), B, Ci, 1, 1, Co, 1, False)
-        ctx.save_for_backward(x, weight)
+        y = conv_fwd_raw(x, packed_weight(weight, w4, 0), None if bias is None else _f32c(bias), B, Ci, 1, 1, Co, 1,
+                         False)
+        ctx.save_for_backward(x, weight, bias)
         ctx.cfg = (B, Ci, Co, bias is not None)
         return y.view(B, Co)
 
     @staticmethod
     @once_differentiable
     def backward(ctx, dy):
-        x, weight = ctx.saved_tensors
+        x, weight, bias = ctx.saved_tensors
         B, Ci, Co, has_bias = ctx.cfg
         dy = _f32c(dy)
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            dx = conv_fwd_raw(dy, pack_weight(weight.view(Co, Ci, 1, 1), 1), None, B, Co, 1, 1, Ci, 1, False).view(B, Ci)
+            dx = conv_fwd_raw(dy, packed_weight(weight, weight.view(Co, Ci, 1, 1), 1), None, B, Co, 1, 1, Ci, 1,
+                              False).view(B, Ci)
         if ctx.needs_input_grad[1]:
-            dw = conv_wgrad_raw(x, dy, B, Ci, 1, 1, Co, 1, False).view(Co, Ci)
+            tgt = _grad_target(weight)
+            if tgt is not None:
+                conv_wgrad_raw(x, dy, B, Ci, 1, 1, Co, 1, False, out=tgt, accumulate=True)
+            else:
+                dw = conv_wgrad_raw(x, dy, B, Ci, 1, 1, Co, 1, False).view(Co, Ci)
         if has_bias and ctx.needs_input_grad[2]:
-            db = bias_grad_raw(dy, B, Co, 1)
+            db = bias_grad_raw(dy, B, Co, 1, _grad_target(bias))
         return dx, dw, db
 
 
@@ -188,13 +251,17 @@ class BnActFn(Function):
         mean = torch.empty((C,), dtype=F32, device=dev)
         rstd = torch.empty((C,), dtype=F32, device=dev)
         world = _world(group) if training else 1
-        if training:
+        if training and world == 1:
+            nws = lib.itcv_bn_workspace(B, C, H * W)
+            ws = _ws(nws, dev)
+            call("itcv_bn_train_stats", ptr(x), B, C, H * W, float(eps), float(momentum), ptr(running_mean),
+                 ptr(running_var), ptr(nbt), ptr(mean), ptr(rstd), ptr(ws), nws, stream())
+        elif training:
             nws = lib.itcv_bn_workspace(B, C, H * W)
             ws = _ws(nws, dev)
             sums = torch.empty((2 * C,), dtype=torch.float64, device=dev)
             call("itcv_bn_moments", ptr(x), ptr(sums), B, C, H * W, ptr(ws), nws, stream())
-            if world > 1:
-                dist.all_reduce(sums, group=group)
+            dist.all_reduce(sums, group=group)
             call("itcv_bn_finalize", ptr(sums), float(B * H * W * world), float(eps), float(momentum),
                  ptr(running_mean), ptr(running_var), ptr(nbt), ptr(mean), ptr(rstd), C, stream())
         else:
@@ -204,6 +271,7 @@ class BnActFn(Function):
         call("itcv_bn_act_fwd", ptr(x), ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), ptr(skip), ptr(y), B, C, H, W,
              float(slope), int(pool), stream())
         ctx.save_for_backward(x, gamma, beta, mean, rstd, skip)
+        ctx.params = (gamma, beta)
         ctx.cfg = (B, C, H, W, float(slope), int(pool), bool(training), group, world)
         ctx.mark_non_differentiable(*[t for t in (running_mean, running_var, nbt) if t is not None])
         return y
@@ -220,18 +288,28 @@ class BnActFn(Function):
         nws = lib.itcv_bn_workspace(B, C, H * W)
         ws = _ws(nws, dev)
         local = torch.empty((2 * C,), dtype=torch.float64, device=dev)
+        # parameter gradients come out of the reduce launch: either added straight into .grad
+        # (solver mode) or into fresh tensors handed to autograd
+        tg = _grad_target(gamma) if ctx.needs_input_grad[1] else None
+        tb = _grad_target(beta) if ctx.needs_input_grad[2] else None
+        direct = tg is not None and tb is not None
+        dgamma = dbeta = None
+        if direct:
+            pg, pb, acc = tg, tb, 1
+        else:
+            dgamma = torch.empty_like(gamma) if ctx.needs_input_grad[1] else None
+            dbeta = torch.empty_like(beta) if ctx.needs_input_grad[2] else None
+            pg, pb, acc = dgamma, dbeta, 0
         call("itcv_bn_act_bwd_reduce", ptr(x), ptr(dy), ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), ptr(skip),
-             ptr(local), B, C, H, W, slope, pool, 0, ptr(ws), nws, stream())
+             ptr(local), ptr(pg), ptr(pb), acc, B, C, H, W, slope, pool, 0, ptr(ws), nws, stream())
         total = local
         if world > 1:
             total = local.clone()
             dist.all_reduce(total, group=group)
         dx = torch.empty_like(x)
         dskip = torch.empty_like(x) if (skip is not None and ctx.needs_input_grad[3]) else None
-        dgamma = torch.empty_like(gamma) if ctx.needs_input_grad[1] else None
-        dbeta = torch.empty_like(beta) if ctx.needs_input_grad[2] else None
         call("itcv_bn_act_bwd_apply", ptr(x), ptr(dy), ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), ptr(skip),
-             ptr(total), ptr(local), float(B * H * W * world), ptr(dx), ptr(dskip), ptr(dgamma), ptr(dbeta), 0, B, C, H,
+             ptr(total), None, float(B * H * W * world), ptr(dx), ptr(dskip), None, None, 0, B, C, H,
              W, slope, pool, 0, stream())
         return (dx, dgamma, dbeta, dskip) + (None,) * 9
 

@@ -10,6 +10,7 @@ import torch
 from torch import Tensor
 
 from hipvae import ddp
+from hipvae.functional import direct_grad_accumulation
 from hipvae.flat import FlatGroup, clip_grad_norm, plain_adam_hparams
 from ops import kl_divergence, reconstruction_loss
 from utils import SingletonWriter
@@ -80,7 +81,8 @@ class VAESolver:
         groups = [self._group(p) for p in parts]
         for g in groups:
             g.zero_grad()
-        loss.backward()
+        with direct_grad_accumulation():     # wgrad / BN / bias kernels add straight into the flat buffers
+            loss.backward()
         for g in groups:
             ddp.average_(g.flat_g)
 

@@ -1,0 +1,129 @@
+"""CPU-only checks of the boundary: the C-ABI library loads and exports every symbol that
+include/itcv_hip.h declares (no compute without a GPU), the ctypes table matches the header, the
+drop-in modules import under the reference's names, parameter initialisation and state_dict keys
+equal the reference's, and the product refuses CPU tensors instead of falling back."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def header_functions():
+    text = open(os.path.join(ROOT, "include", "itcv_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(itcv_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from hipvae import abi
+    lib = ctypes.CDLL(abi.LIB_PATH)
+    names = header_functions()
+    assert len(names) >= 45
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/itcv_hip.h but not exported"
+    assert sorted(abi.SIGNATURES) == names, "ctypes table and header disagree"
+    assert lib.itcv_abi_version() == abi.ABI_VERSION == int(
+        re.search(r"#define ITCV_ABI_VERSION (\d+)", open(os.path.join(ROOT, "include", "itcv_hip.h")).read()).group(1))
+
+
+def test_host_side_argument_checks_need_no_gpu():
+    from hipvae import abi
+    # pure host queries
+    assert abi.lib.itcv_conv2d_packed_weight_elems(64, 3, 5, 0) == 25 * 16 * 64
+    assert abi.lib.itcv_conv2d_packed_weight_elems(64, 3, 5, 1) == 25 * 64 * 32
+    assert abi.lib.itcv_conv2d_fwd_workspace(64, 512, 4, 4, 512, 3) > 0
+    assert abi.lib.itcv_conv2d_fwd_workspace(64, 64, 64, 64, 64, 3) == 0
+    assert abi.lib.itcv_tc_bwd_workspace(64, 512) == 64 * 512 * 4
+    # argument validation happens before any launch
+    assert abi.lib.itcv_conv2d_fwd(None, None, None, None, 1, 1, 1, 1, 1, 7, 0, None, 0, None) != 0
+    assert "kernel size" in abi.last_error()
+    assert abi.lib.itcv_tc_fwd(None, None, None, None, None, None, 4, 4, 0, 8, 100, 3, None) != 0
+    with pytest.raises(RuntimeError):
+        abi.call("itcv_adam_step", None, None, None, None, 10, 1e-3, 0.9, 0.999, 1e-8, 1, None)
+
+
+def test_no_cpu_fallback():
+    import ops
+    from hipvae import abi
+    with pytest.raises(abi.HipExtensionError):
+        ops.kl_divergence(torch.zeros(2, 3), torch.zeros(2, 3))
+    with pytest.raises(abi.HipExtensionError):
+        ops.reconstruction_loss(torch.zeros(2, 3), torch.zeros(2, 3))
+    src = ""
+    for dp, _, fs in os.walk(os.path.join(ROOT, "intro-tc-vae_amd")):
+        for f in fs:
+            if f.endswith(".py"):
+                src += open(os.path.join(dp, f)).read()
+    assert "import oracle" not in src and "from oracle" not in src, "the product must not touch the oracle"
+
+
+@pytest.mark.parametrize("arch", ["conv", "res"])
+def test_init_and_state_dict_equal_reference(arch):
+    import models
+    g = np.load(os.path.join(GOLDEN, f"model_{arch}.npz"))
+    torch.manual_seed(0)
+    m = models.SoftIntroVAE(arch=arch, cdim=3, zdim=10, channels=(8, 16, 32), image_size=32)
+    ref_keys = [k[5:].replace("/", ".") for k in g.files if k.startswith("init:")]
+    sd = m.state_dict()
+    assert list(sd.keys()) == ref_keys
+    for k in ref_keys:
+        assert np.array_equal(sd[k].numpy(), g["init:" + k.replace(".", "/")]), k
+    assert m.zdim == 10 and m.cdim == 3 and m.encoder.image_size == 32
+    assert len(list(m.encoder.fc.parameters())) == 2
+    enc, dec = set(map(id, m.encoder.parameters())), set(map(id, m.decoder.parameters()))
+    assert not (enc & dec)
+
+
+def test_reference_surface():
+    import inspect
+    import models
+    import ops
+    import utils
+    from solvers import IntroSolver, VAESolver
+    from solvers.intro_tc import IntroTCSovler
+    from solvers.tc import TCSovler
+    assert issubclass(TCSovler, VAESolver) and issubclass(IntroTCSovler, IntroSolver) and issubclass(IntroSolver, VAESolver)
+    assert list(inspect.signature(VAESolver.__init__).parameters)[1:] == [
+        "dataset", "model", "batch_size", "optimizer_e", "optimizer_d", "recon_loss_type", "beta_kl", "beta_rec",
+        "device", "use_amp", "grad_scaler", "writer", "test_iter", "clip"]
+    assert list(inspect.signature(IntroSolver.__init__).parameters)[1:] == [
+        "dataset", "model", "batch_size", "optimizer_e", "optimizer_d", "recon_loss_type", "beta_kl", "beta_rec",
+        "beta_neg", "gamma_r", "device", "use_amp", "grad_scaler", "writer", "test_iter", "clip"]
+    assert list(inspect.signature(VAESolver.compute_kl_loss).parameters) == ["self", "z", "mu", "logvar", "reduce", "beta", "write"]
+    assert list(inspect.signature(VAESolver.compute_rec_loss).parameters) == ["self", "x", "recon_x", "reduction", "beta", "write"]
+    for name in ("reparameterize", "reconstruction_loss", "kl_divergence", "kl_no_reduce", "total_correlation",
+                 "log_importance_weight_matrix", "entropy"):
+        assert hasattr(ops, name)
+    with pytest.raises(ValueError):
+        models.get_conv_class("mlp")
+    with pytest.raises(TypeError):
+        ops.entropy([0.5, 0.5])
+    assert abs(ops.entropy(np.array([0.5, 0.5]), base=2) - 1.0) < 1e-6
+    d = utils.LossDict(a=1.0, b=2.0) + utils.LossDict(a=3.0)
+    assert d == {"a": 4.0, "b": 2.0} and (d / 2)["a"] == 2.0
+    assert utils.SingletonWriter() is utils.SingletonWriter()
+    w = ops.log_importance_weight_matrix(4, 100).exp()
+    assert torch.allclose(w[:, 0], torch.tensor([0.01, 0.01, 97 / 300, 0.01]), atol=1e-6)
+
+
+def test_checkpoint_roundtrip(tmp_path, monkeypatch):
+    """utils.py:26-36 / :10-12 format: {"epoch", "model": state_dict} with the reference's keys."""
+    import models
+    import utils
+    monkeypatch.chdir(tmp_path)
+    torch.manual_seed(1)
+    m = models.SoftIntroVAE(arch="conv", cdim=3, zdim=10, channels=(8, 16), image_size=16)
+    utils.save_checkpoint(m, 3, 7, "t_")
+    path = os.path.join("saves", "t_model_epoch_3_iter_7.pth")
+    blob = torch.load(path, weights_only=True)
+    assert blob["epoch"] == 3 and "encoder.main.0.weight" in blob["model"]
+    m2 = models.SoftIntroVAE(arch="conv", cdim=3, zdim=10, channels=(8, 16), image_size=16)
+    utils.load_model(m2, path, "cpu")
+    for (k, a), (_, b) in zip(m.state_dict().items(), m2.state_dict().items()):
+        assert torch.equal(a, b), k

@@ -164,7 +164,7 @@ def test_bn_upsampled_gradient_mode(HF):
         ws = torch.empty(nws, dtype=torch.uint8, device=d)
         sums = torch.empty(2 * C, dtype=torch.float64, device=d)
         call("itcv_bn_act_bwd_reduce", ptr(x), ptr(dy), ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), None, ptr(sums),
-             B, C, H, W, 0.2, 0, up2, ptr(ws), nws, stream())
+             None, None, 0, B, C, H, W, 0.2, 0, up2, ptr(ws), nws, stream())
         dx = torch.empty_like(x)
         call("itcv_bn_act_bwd_apply", ptr(x), ptr(dy), ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), None, ptr(sums),
              None, float(B * H * W), ptr(dx), None, None, None, 0, B, C, H, W, 0.2, 0, up2, stream())
