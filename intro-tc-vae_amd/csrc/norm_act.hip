@@ -8,28 +8,30 @@ namespace itcv {
 
 constexpr int kRedThreads = 256;
 
+// division by a runtime constant that is usually a power of two (sh = log2 or -1)
+__device__ __forceinline__ uint32_t fdiv(uint32_t a, uint32_t d, int sh) { return sh >= 0 ? (a >> sh) : (a / d); }
+
 // ------------------------------------------------------------------ channel moments (fp64)
 // grid (C, splits): block (c, s) reduces its slice of channel c's B*HW values
 __global__ __launch_bounds__(kRedThreads) void bn_moments_partial(const float* __restrict__ x,
                                                                   double* __restrict__ part, int B, int C, int HW,
-                                                                  int splits) {
+                                                                  int splits, int hw_shift) {
   __shared__ double scratch[kRedThreads / 64];
-  const int c = blockIdx.x, s = blockIdx.y;
-  const size_t total = (size_t)B * HW;
-  const size_t chunk = ((total + splits - 1) / splits + 3) & ~(size_t)3;  // multiple of 4: float4 stays aligned
-  const size_t beg = (size_t)s * chunk, end = beg + chunk < total ? beg + chunk : total;
+  const uint32_t c = blockIdx.x, s = blockIdx.y, hw_n = HW, total = (uint32_t)B * hw_n;
+  const uint32_t chunk = ((total + splits - 1) / splits + 3) & ~3u;  // multiple of 4: float4 stays aligned
+  const uint32_t beg = s * chunk, end = min(beg + chunk, total);
   double s1 = 0.0, s2 = 0.0;
   if ((HW & 3) == 0) {
-    for (size_t i = beg + (size_t)threadIdx.x * 4; i < end; i += (size_t)kRedThreads * 4) {
-      const size_t b = i / HW, hw = i - b * HW;
-      const float4 v = *reinterpret_cast<const float4*>(x + (b * C + c) * HW + hw);
-      s1 += (double)v.x + (double)v.y + (double)v.z + (double)v.w;
-      s2 += (double)v.x * v.x + (double)v.y * v.y + (double)v.z * v.z + (double)v.w * v.w;
+    for (uint32_t i = beg + threadIdx.x * 4; i < end; i += kRedThreads * 4) {
+      const uint32_t b = fdiv(i, hw_n, hw_shift), hw = i - b * hw_n;
+      const float4 v = *reinterpret_cast<const float4*>(x + ((size_t)b * C + c) * hw_n + hw);
+      s1 += ((double)v.x + (double)v.y) + ((double)v.z + (double)v.w);
+      s2 += ((double)v.x * v.x + (double)v.y * v.y) + ((double)v.z * v.z + (double)v.w * v.w);
     }
   } else {
-    for (size_t i = beg + threadIdx.x; i < end; i += kRedThreads) {
-      const size_t b = i / HW, hw = i - b * HW;
-      const float v = x[(b * C + c) * HW + hw];
+    for (uint32_t i = beg + threadIdx.x; i < end; i += kRedThreads) {
+      const uint32_t b = fdiv(i, hw_n, hw_shift), hw = i - b * hw_n;
+      const float v = x[((size_t)b * C + c) * hw_n + hw];
       s1 += (double)v;
       s2 += (double)v * v;
     }
@@ -124,13 +126,15 @@ template <int POOL>
 __global__ void bn_act_fwd_kernel(const float* __restrict__ x, const float* __restrict__ mean,
                                   const float* __restrict__ rstd, const float* __restrict__ gamma,
                                   const float* __restrict__ beta, const float* __restrict__ skip,
-                                  float* __restrict__ y, int C, int H, int W, size_t nout, float slope) {
+                                  float* __restrict__ y, int C, int H, int W, size_t nout, float slope,
+                                  int hw_shift, int c_mask) {
   const int HW = H * W;
   if (POOL == 0) {
     // 4 consecutive pixels per thread (HW % 4 == 0 is checked on the host)
     for (size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < nout;
          i += (size_t)gridDim.x * blockDim.x * 4) {
-      const int c = (int)((i / HW) % C);
+      const uint32_t pl = fdiv((uint32_t)i, HW, hw_shift);
+      const int c = c_mask >= 0 ? (int)(pl & (uint32_t)c_mask) : (int)(pl % (uint32_t)C);
       const float sc = gamma[c] * rstd[c], sh = beta[c] - mean[c] * sc;
       float4 v = *reinterpret_cast<const float4*>(x + i);
       v.x = v.x * sc + sh, v.y = v.y * sc + sh, v.z = v.z * sc + sh, v.w = v.w * sc + sh;
@@ -144,11 +148,11 @@ __global__ void bn_act_fwd_kernel(const float* __restrict__ x, const float* __re
   } else {
     const int Ho = H / 2, Wo = W / 2, HWo = Ho * Wo;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nout; i += (size_t)gridDim.x * blockDim.x) {
-      const size_t bc = i / HWo;
-      const int r = (int)(i - bc * HWo), ho = r / Wo, wo = r - ho * Wo;
-      const int c = (int)(bc % C);
+      const uint32_t bc = hw_shift >= 2 ? ((uint32_t)i >> (hw_shift - 2)) : (uint32_t)i / (uint32_t)HWo;
+      const int r = (int)((uint32_t)i - bc * HWo), ho = r / Wo, wo = r - ho * Wo;
+      const int c = c_mask >= 0 ? (int)(bc & (uint32_t)c_mask) : (int)(bc % (uint32_t)C);
       const float sc = gamma[c] * rstd[c], sh = beta[c] - mean[c] * sc;
-      const size_t src = bc * HW + (size_t)(2 * ho) * W + 2 * wo;
+      const size_t src = (size_t)bc * HW + (size_t)(2 * ho) * W + 2 * wo;
       const float2 a = *reinterpret_cast<const float2*>(x + src);
       const float2 b = *reinterpret_cast<const float2*>(x + src + W);
       float v0 = a.x * sc + sh, v1 = a.y * sc + sh, v2 = b.x * sc + sh, v3 = b.y * sc + sh;
@@ -237,6 +241,98 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ x, const float* __
   }
 }
 
+
+// ---- vectorised (float4) backward kernels: W % 4 == 0, tensors < 2^31 elements ------------------
+
+// upstream gradient of the 4 consecutive pixels (h, w..w+3) of plane bc (see upstream<MODE>)
+template <int MODE>
+__device__ __forceinline__ float4 upstream4(const float* __restrict__ dy, uint32_t bc, uint32_t h, uint32_t w,
+                                            uint32_t H, uint32_t W) {
+  if (MODE == 0) return *reinterpret_cast<const float4*>(dy + (size_t)bc * H * W + h * W + w);
+  if (MODE == 1) {
+    const float2 d = *reinterpret_cast<const float2*>(dy + (size_t)bc * (H / 2) * (W / 2) + (h >> 1) * (W / 2) + (w >> 1));
+    return make_float4(0.25f * d.x, 0.25f * d.x, 0.25f * d.y, 0.25f * d.y);
+  }
+  const float* p = dy + (size_t)bc * (4 * H * W) + (size_t)(2 * h) * (2 * W) + 2 * w;
+  const float4 a0 = *reinterpret_cast<const float4*>(p), a1 = *reinterpret_cast<const float4*>(p + 4);
+  const float4 b0 = *reinterpret_cast<const float4*>(p + 2 * W), b1 = *reinterpret_cast<const float4*>(p + 2 * W + 4);
+  return make_float4((a0.x + a0.y) + (b0.x + b0.y), (a0.z + a0.w) + (b0.z + b0.w), (a1.x + a1.y) + (b1.x + b1.y),
+                     (a1.z + a1.w) + (b1.z + b1.w));
+}
+
+template <int MODE>
+__global__ __launch_bounds__(kRedThreads) void bn_bwd_partial_v4(
+    const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ mean,
+    const float* __restrict__ rstd, const float* __restrict__ gamma, const float* __restrict__ beta,
+    const float* __restrict__ skip, double* __restrict__ part, int B, int C, int H, int W, float slope, int splits,
+    int w_shift, int hw_shift) {
+  __shared__ double scratch[kRedThreads / 64];
+  const uint32_t c = blockIdx.x, s = blockIdx.y, HW = H * W, total = (uint32_t)B * HW;
+  const uint32_t chunk = ((total + splits - 1) / splits + 3) & ~3u;
+  const uint32_t beg = s * chunk, end = min(beg + chunk, total);
+  const float mu = mean[c], rs = rstd[c], ga = gamma[c], be = beta[c];
+  double s1 = 0.0, s2 = 0.0;
+  for (uint32_t i = beg + threadIdx.x * 4; i < end; i += kRedThreads * 4) {
+    const uint32_t b = fdiv(i, HW, hw_shift), hw = i - b * HW;
+    const uint32_t h = fdiv(hw, W, w_shift), w = hw - h * W;
+    const uint32_t bc = b * C + c;
+    const size_t off = (size_t)bc * HW + hw;
+    const float4 xv = *reinterpret_cast<const float4*>(x + off);
+    float4 g = upstream4<MODE>(dy, bc, h, w, H, W);
+    const float xh0 = (xv.x - mu) * rs, xh1 = (xv.y - mu) * rs, xh2 = (xv.z - mu) * rs, xh3 = (xv.w - mu) * rs;
+    float u0 = xh0 * ga + be, u1 = xh1 * ga + be, u2 = xh2 * ga + be, u3 = xh3 * ga + be;
+    if (skip) {
+      const float4 k = *reinterpret_cast<const float4*>(skip + off);
+      u0 += k.x, u1 += k.y, u2 += k.z, u3 += k.w;
+    }
+    if (!(u0 > 0.f)) g.x *= slope;
+    if (!(u1 > 0.f)) g.y *= slope;
+    if (!(u2 > 0.f)) g.z *= slope;
+    if (!(u3 > 0.f)) g.w *= slope;
+    s1 += ((double)g.x + (double)g.y) + ((double)g.z + (double)g.w);
+    s2 += ((double)g.x * xh0 + (double)g.y * xh1) + ((double)g.z * xh2 + (double)g.w * xh3);
+  }
+  s1 = block_sum(s1, scratch);
+  s2 = block_sum(s2, scratch);
+  if (threadIdx.x == 0) {
+    part[((size_t)s * 2 + 0) * C + c] = s1;
+    part[((size_t)s * 2 + 1) * C + c] = s2;
+  }
+}
+
+template <int MODE>
+__global__ void bn_bwd_apply_v4(const float* __restrict__ x, const float* __restrict__ dy,
+                                const float* __restrict__ mean, const float* __restrict__ rstd,
+                                const float* __restrict__ gamma, const float* __restrict__ beta,
+                                const float* __restrict__ skip, const double* __restrict__ dsums, double count,
+                                float* __restrict__ dx, float* __restrict__ dskip, int C, int H, int W, uint32_t n4,
+                                float slope, int w_shift, int hw_shift, int c_mask) {
+  const uint32_t HW = H * W;
+  for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < n4; j += gridDim.x * blockDim.x) {
+    const uint32_t i = j * 4;
+    const uint32_t bc = fdiv(i, HW, hw_shift), hw = i - bc * HW;
+    const uint32_t h = fdiv(hw, W, w_shift), w = hw - h * W;
+    const uint32_t c = c_mask >= 0 ? (bc & (uint32_t)c_mask) : (bc % (uint32_t)C);
+    const float mu = mean[c], rs = rstd[c], ga = gamma[c], be = beta[c];
+    const float m1 = (float)(dsums[c] / count), m2 = (float)(dsums[C + c] / count), gr = ga * rs;
+    const float4 xv = *reinterpret_cast<const float4*>(x + i);
+    float4 g = upstream4<MODE>(dy, bc, h, w, H, W);
+    const float xh0 = (xv.x - mu) * rs, xh1 = (xv.y - mu) * rs, xh2 = (xv.z - mu) * rs, xh3 = (xv.w - mu) * rs;
+    float u0 = xh0 * ga + be, u1 = xh1 * ga + be, u2 = xh2 * ga + be, u3 = xh3 * ga + be;
+    if (skip) {
+      const float4 k = *reinterpret_cast<const float4*>(skip + i);
+      u0 += k.x, u1 += k.y, u2 += k.z, u3 += k.w;
+    }
+    if (!(u0 > 0.f)) g.x *= slope;
+    if (!(u1 > 0.f)) g.y *= slope;
+    if (!(u2 > 0.f)) g.z *= slope;
+    if (!(u3 > 0.f)) g.w *= slope;
+    *reinterpret_cast<float4*>(dx + i) = make_float4(gr * (g.x - m1 - xh0 * m2), gr * (g.y - m1 - xh1 * m2),
+                                                     gr * (g.z - m1 - xh2 * m2), gr * (g.w - m1 - xh3 * m2));
+    if (dskip) *reinterpret_cast<float4*>(dskip + i) = g;
+  }
+}
+
 __global__ void bn_param_grad_kernel(const double* __restrict__ local, float* dgamma, float* dbeta, int C,
                                      int accumulate) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -309,6 +405,13 @@ __global__ void upsample2_bwd_kernel(const float* __restrict__ dy, float* __rest
   }
 }
 
+static inline int ilog2_exact(int v) {
+  if (v <= 0 || (v & (v - 1))) return -1;
+  int sh = 0;
+  while ((1 << sh) < v) ++sh;
+  return sh;
+}
+
 static inline int grid_for(size_t n, int per_thread = 1) {
   size_t b = cdivz(cdivz(n, per_thread), 256);
   if (b > 256 * 8) b = 256 * 8;  // grid-stride the rest (>= 8 blocks per CU resident)
@@ -341,7 +444,8 @@ int itcv_bn_moments(const float* x, double* sums, int B, int C, int HW, void* ws
   const int splits = bn_splits(B, C, HW);
   ITCV_REQUIRE(ws && ws_bytes >= (size_t)splits * 2 * C * sizeof(double), "itcv_bn_moments(workspace)");
   double* part = static_cast<double*>(ws);
-  hipLaunchKernelGGL(bn_moments_partial, dim3(C, splits), dim3(kRedThreads), 0, S(stream), x, part, B, C, HW, splits);
+  hipLaunchKernelGGL(bn_moments_partial, dim3(C, splits), dim3(kRedThreads), 0, S(stream), x, part, B, C, HW, splits,
+                     ilog2_exact(HW));
   ITCV_CHECK_LAUNCH("itcv_bn_moments");
   hipLaunchKernelGGL(combine_partials, dim3(cdiv(2 * C, 256)), dim3(256), 0, S(stream), part, sums, 2 * C, splits);
   ITCV_CHECK_LAUNCH("itcv_bn_moments(combine)");
@@ -355,7 +459,8 @@ int itcv_bn_train_stats(const float* x, int B, int C, int HW, float eps, float m
   const int splits = bn_splits(B, C, HW);
   ITCV_REQUIRE(ws && ws_bytes >= (size_t)splits * 2 * C * sizeof(double), "itcv_bn_train_stats(workspace)");
   double* part = static_cast<double*>(ws);
-  hipLaunchKernelGGL(bn_moments_partial, dim3(C, splits), dim3(kRedThreads), 0, S(stream), x, part, B, C, HW, splits);
+  hipLaunchKernelGGL(bn_moments_partial, dim3(C, splits), dim3(kRedThreads), 0, S(stream), x, part, B, C, HW, splits,
+                     ilog2_exact(HW));
   ITCV_CHECK_LAUNCH("itcv_bn_train_stats");
   hipLaunchKernelGGL(bn_combine_finalize_kernel, dim3(cdiv(C, 256)), dim3(256), 0, S(stream), part, splits,
                      (double)B * HW, eps, momentum, running_mean, running_var, num_batches_tracked, mean, rstd, C);
@@ -385,16 +490,17 @@ int itcv_bn_eval_stats(const float* running_mean, const float* running_var, floa
 int itcv_bn_act_fwd(const float* x, const float* mean, const float* rstd, const float* gamma, const float* beta,
                     const float* skip, float* y, int B, int C, int H, int W, float slope, int pool, void* stream) {
   ITCV_REQUIRE(x && mean && rstd && gamma && beta && y && B > 0 && C > 0 && H > 0 && W > 0, "itcv_bn_act_fwd");
+  ITCV_REQUIRE((size_t)B * C * H * W < (1ull << 31), "itcv_bn_act_fwd(tensor < 2^31 elements)");
   if (pool) {
     ITCV_REQUIRE(H % 2 == 0 && W % 2 == 0, "itcv_bn_act_fwd(pool)");
     const size_t nout = (size_t)B * C * (H / 2) * (W / 2);
     hipLaunchKernelGGL(bn_act_fwd_kernel<1>, dim3(grid_for(nout)), dim3(256), 0, S(stream), x, mean, rstd, gamma,
-                       beta, skip, y, C, H, W, nout, slope);
+                       beta, skip, y, C, H, W, nout, slope, ilog2_exact(H * W), ilog2_exact(C) >= 0 ? C - 1 : -1);
   } else {
     ITCV_REQUIRE((H * W) % 4 == 0, "itcv_bn_act_fwd(H*W % 4)");
     const size_t nout = (size_t)B * C * H * W;
     hipLaunchKernelGGL(bn_act_fwd_kernel<0>, dim3(grid_for(nout, 4)), dim3(256), 0, S(stream), x, mean, rstd, gamma,
-                       beta, skip, y, C, H, W, nout, slope);
+                       beta, skip, y, C, H, W, nout, slope, ilog2_exact(H * W), ilog2_exact(C) >= 0 ? C - 1 : -1);
   }
   ITCV_CHECK_LAUNCH("itcv_bn_act_fwd");
   return 0;
@@ -411,15 +517,25 @@ int itcv_bn_act_bwd_reduce(const float* x, const float* dy, const float* mean, c
   ITCV_REQUIRE(ws && ws_bytes >= (size_t)splits * 2 * C * sizeof(double), "itcv_bn_act_bwd_reduce(workspace)");
   double* part = static_cast<double*>(ws);
   dim3 grid(C, splits);
+  const bool vec = (W % 4 == 0) && ((size_t)B * C * H * W < (1ull << 31));
+  const int wsh = ilog2_exact(W), hwsh = ilog2_exact(H * W);
+  hipStream_t st = S(stream);
+#define ITCV_BWD_PARTIAL(MODE)                                                                                   \
+  do {                                                                                                           \
+    if (vec)                                                                                                     \
+      hipLaunchKernelGGL(bn_bwd_partial_v4<MODE>, grid, dim3(kRedThreads), 0, st, x, dy, mean, rstd, gamma, beta, \
+                         skip, part, B, C, H, W, slope, splits, wsh, hwsh);                                      \
+    else                                                                                                         \
+      hipLaunchKernelGGL(bn_bwd_partial<MODE>, grid, dim3(kRedThreads), 0, st, x, dy, mean, rstd, gamma, beta,    \
+                         skip, part, B, C, H, W, slope, splits);                                                 \
+  } while (0)
   if (pool)
-    hipLaunchKernelGGL(bn_bwd_partial<1>, grid, dim3(kRedThreads), 0, S(stream), x, dy, mean, rstd, gamma, beta, skip,
-                       part, B, C, H, W, slope, splits);
+    ITCV_BWD_PARTIAL(1);
   else if (up2)
-    hipLaunchKernelGGL(bn_bwd_partial<2>, grid, dim3(kRedThreads), 0, S(stream), x, dy, mean, rstd, gamma, beta, skip,
-                       part, B, C, H, W, slope, splits);
+    ITCV_BWD_PARTIAL(2);
   else
-    hipLaunchKernelGGL(bn_bwd_partial<0>, grid, dim3(kRedThreads), 0, S(stream), x, dy, mean, rstd, gamma, beta, skip,
-                       part, B, C, H, W, slope, splits);
+    ITCV_BWD_PARTIAL(0);
+#undef ITCV_BWD_PARTIAL
   ITCV_CHECK_LAUNCH("itcv_bn_act_bwd_reduce");
   hipLaunchKernelGGL(bn_combine_param_kernel, dim3(cdiv(C, 256)), dim3(256), 0, S(stream), part, dsums, C, splits,
                      dgamma, dbeta, accumulate);
@@ -435,16 +551,25 @@ int itcv_bn_act_bwd_apply(const float* x, const float* dy, const float* mean, co
                "itcv_bn_act_bwd_apply");
   ITCV_REQUIRE(!(pool && up2), "itcv_bn_act_bwd_apply(pool and up2 are exclusive)");
   const size_t n = (size_t)B * C * H * W;
-  dim3 grid(grid_for(n));
+  const bool vec = (W % 4 == 0) && (n < (1ull << 31));
+  const int wsh = ilog2_exact(W), hwsh = ilog2_exact(H * W), cmask = ilog2_exact(C) >= 0 ? C - 1 : -1;
+  hipStream_t st = S(stream);
+#define ITCV_BWD_APPLY(MODE)                                                                                      \
+  do {                                                                                                            \
+    if (vec)                                                                                                      \
+      hipLaunchKernelGGL(bn_bwd_apply_v4<MODE>, dim3(grid_for(n, 4)), dim3(256), 0, st, x, dy, mean, rstd, gamma,  \
+                         beta, skip, dsums, count, dx, dskip, C, H, W, (uint32_t)(n / 4), slope, wsh, hwsh, cmask); \
+    else                                                                                                          \
+      hipLaunchKernelGGL(bn_bwd_apply_kernel<MODE>, dim3(grid_for(n)), dim3(256), 0, st, x, dy, mean, rstd, gamma, \
+                         beta, skip, dsums, count, dx, dskip, C, H, W, n, slope);                                 \
+  } while (0)
   if (pool)
-    hipLaunchKernelGGL(bn_bwd_apply_kernel<1>, grid, dim3(256), 0, S(stream), x, dy, mean, rstd, gamma, beta, skip,
-                       dsums, count, dx, dskip, C, H, W, n, slope);
+    ITCV_BWD_APPLY(1);
   else if (up2)
-    hipLaunchKernelGGL(bn_bwd_apply_kernel<2>, grid, dim3(256), 0, S(stream), x, dy, mean, rstd, gamma, beta, skip,
-                       dsums, count, dx, dskip, C, H, W, n, slope);
+    ITCV_BWD_APPLY(2);
   else
-    hipLaunchKernelGGL(bn_bwd_apply_kernel<0>, grid, dim3(256), 0, S(stream), x, dy, mean, rstd, gamma, beta, skip,
-                       dsums, count, dx, dskip, C, H, W, n, slope);
+    ITCV_BWD_APPLY(0);
+#undef ITCV_BWD_APPLY
   ITCV_CHECK_LAUNCH("itcv_bn_act_bwd_apply");
   if (dgamma || dbeta) {
     hipLaunchKernelGGL(bn_param_grad_kernel, dim3(cdiv(C, 256)), dim3(256), 0, S(stream),
