@@ -183,6 +183,10 @@ int itcv_scale_by_dev(float* x, size_t n, const float* coef_dev, void* stream);
 /* torch.optim.Adam defaults (no amsgrad / weight decay), one flat launch; step is 1-based */
 int itcv_adam_step(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1,
                    float beta2, float eps, int step, void* stream);
+/* same update with the 0-based count of completed steps read from (and incremented in) device
+ * memory, so that a captured launch (hipGraph replay) advances the bias correction */
+int itcv_adam_step_dev(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1,
+                       float beta2, float eps, int* step_dev, void* stream);
 int itcv_fill(float* x, size_t n, float value, void* stream);
 
 #ifdef __cplusplus

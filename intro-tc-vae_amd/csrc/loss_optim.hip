@@ -127,6 +127,25 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
     p[i] -= step_size * (mi / (sqrtf(vi) / sqrt_bc2 + eps));
   }
 }
+// graph-replay-safe variant: the step count lives in device memory (a captured launch would freeze
+// a host-side count); bias corrections are evaluated per thread in fp64 like torch's Python floats
+__global__ void adam_dev_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                float* __restrict__ v, size_t n, float lr, float b1, float b2, float eps,
+                                const int* __restrict__ step_dev) {
+  const int step = step_dev[0] + 1;
+  const double bc1 = 1.0 - pow((double)b1, (double)step), bc2 = 1.0 - pow((double)b2, (double)step);
+  const float step_size = (float)((double)lr / bc1), sqrt_bc2 = (float)sqrt(bc2);
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const float gi = g[i];
+    const float mi = m[i] + (1.f - b1) * (gi - m[i]);
+    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    p[i] -= step_size * (mi / (sqrtf(vi) / sqrt_bc2 + eps));
+  }
+}
+__global__ void bump_step_kernel(int* step_dev) { step_dev[0] += 1; }
+
 __global__ void fill_kernel(float* __restrict__ x, size_t n, float value) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
     x[i] = value;
@@ -231,6 +250,18 @@ int itcv_adam_step(float* p, const float* g, float* m, float* v, size_t n, float
   hipLaunchKernelGGL(adam_kernel, dim3(stream_grid(n, 1)), dim3(256), 0, S(stream), p, g, m, v, n, step_size, beta1,
                      beta2, eps, sqrt_bc2);
   ITCV_CHECK_LAUNCH("itcv_adam_step");
+  return 0;
+}
+
+int itcv_adam_step_dev(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2,
+                       float eps, int* step_dev, void* stream) {
+  ITCV_REQUIRE(p && g && m && v && step_dev, "itcv_adam_step_dev");
+  if (!n) return 0;
+  hipLaunchKernelGGL(adam_dev_kernel, dim3(stream_grid(n, 1)), dim3(256), 0, S(stream), p, g, m, v, n, lr, beta1, beta2,
+                     eps, step_dev);
+  ITCV_CHECK_LAUNCH("itcv_adam_step_dev");
+  hipLaunchKernelGGL(bump_step_kernel, dim3(1), dim3(1), 0, S(stream), step_dev);
+  ITCV_CHECK_LAUNCH("itcv_adam_step_dev(bump)");
   return 0;
 }
 

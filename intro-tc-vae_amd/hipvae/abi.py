@@ -72,6 +72,7 @@ SIGNATURES = {
     "itcv_clip_coef": (i32, [p, i32, f64, p, p, p]),
     "itcv_scale_by_dev": (i32, [p, sz, p, p]),
     "itcv_adam_step": (i32, [p, p, p, p, sz, f32, f32, f32, f32, i32, p]),
+    "itcv_adam_step_dev": (i32, [p, p, p, p, sz, f32, f32, f32, f32, p, p]),
     "itcv_fill": (i32, [p, sz, f32, p]),
 }
 

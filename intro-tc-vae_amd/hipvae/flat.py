@@ -28,7 +28,8 @@ class FlatGroup:
         self.flat_g = torch.zeros(total, dtype=F32, device=dev)
         self.exp_avg = torch.zeros(total, dtype=F32, device=dev)
         self.exp_avg_sq = torch.zeros(total, dtype=F32, device=dev)
-        self.step = 0
+        self.step = 0                                      # host mirror (not advanced by graph replays)
+        self.step_dev = torch.zeros(1, dtype=torch.int32, device=dev)   # authoritative step count
         with torch.no_grad():
             for p, o in zip(self.params, self.offsets):
                 n = p.numel()
@@ -60,8 +61,8 @@ class FlatGroup:
 
     def adam_step(self, lr, betas=(0.9, 0.999), eps=1e-8):
         self.step += 1
-        call("itcv_adam_step", ptr(self.flat_p), ptr(self.flat_g), ptr(self.exp_avg), ptr(self.exp_avg_sq),
-             self.numel, float(lr), float(betas[0]), float(betas[1]), float(eps), self.step, stream())
+        call("itcv_adam_step_dev", ptr(self.flat_p), ptr(self.flat_g), ptr(self.exp_avg), ptr(self.exp_avg_sq),
+             self.numel, float(lr), float(betas[0]), float(betas[1]), float(eps), ptr(self.step_dev), stream())
         bump_weight_epoch()          # parameters changed behind torch's back: drop packed-weight caches
 
 

@@ -30,13 +30,11 @@ class IntroSolver(VAESolver):
             rec_rows = rec_rows.sum(-1)
         return (-2 * self.scale * (rec_rows + kl_rows)).exp().mean()
 
-    def train_step(self, batch: Tensor, cur_iter: int) -> dict:
-        if batch.dim() == 3:
-            batch = batch.unsqueeze(0)
+    def _device_step(self, real: Tensor) -> Tensor:
+        """Everything of intro.py:56-160 that runs on the device; returns the stats vector
+        [loss_enc, loss_dec, loss_kl, loss_rec, expelbo_fake, lossD_fake_kl, norm_E, norm_D]."""
         model, scale = self.model, self.scale
-        noise_batch = noise((batch.size(0), model.zdim), self.device)               # intro.py:61
-        real = batch.to(self.device)
-
+        noise_batch = noise((real.size(0), model.zdim), self.device)               # intro.py:61
         # ================= update E (decoder frozen) ======================== intro.py:65-116
         self._set_trainable(encoder=True, decoder=False)
         fake = model.sample(noise_batch)
@@ -77,11 +75,19 @@ class IntroSolver(VAESolver):
         norm_d = self._clip()
         self._step("decoder")
 
-        # ================= one read-back, NaN check, logging ================ intro.py:162-196
         stats = torch.stack([loss_e.detach(), loss_d.detach(), loss_e_real_kl.detach(), loss_rec.detach(),
                              expelbo_fake.detach(), loss_d_fake_kl.detach()])
         ddp.mean_scalars_(stats)
-        v_e, v_d, v_kl, v_rec, v_expf, v_dfkl, v_ne, v_nd = self._read(*stats.unbind(0), norm_e, norm_d)
+        zero = stats.new_zeros(1)
+        self._last_fake = fake.detach() if self.writer else None
+        return torch.cat([stats, norm_e if norm_e is not None else zero, norm_d if norm_d is not None else zero])
+
+    def train_step(self, batch: Tensor, cur_iter: int) -> dict:
+        if batch.dim() == 3:
+            batch = batch.unsqueeze(0)
+        real = batch.to(self.device)
+        # ================= one read-back, NaN check, logging ================ intro.py:162-196
+        v_e, v_d, v_kl, v_rec, v_expf, v_dfkl, v_ne, v_nd = self._run(real).tolist()
         if v_e != v_e or v_d != v_d:
             raise RuntimeError
         if self.writer:
@@ -92,7 +98,7 @@ class IntroSolver(VAESolver):
             self.writer.add_scalar("lossE", v_e, global_step=cur_iter)
             self.writer.add_scalar("lossD", v_d, global_step=cur_iter)
             self.write_gradient_norm(cur_iter)
-            self.write_images(real, fake, cur_iter)
+            self.write_images(real, self._last_fake, cur_iter)
             self.write_disentanglemnt_scores(cur_iter)
             self.writer.flush()
         return {"loss_enc": v_e, "loss_dec": v_d, "loss_kl": v_kl, "loss_rec": v_rec,

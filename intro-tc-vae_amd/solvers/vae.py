@@ -101,18 +101,47 @@ class VAESolver:
         else:
             self._group(part).adam_step(*hp)
 
-    @staticmethod
-    def _read(*scalars):
-        """One device->host transfer for every scalar the step returns (the reference syncs >= 6x)."""
-        vals = torch.stack([s.detach().reshape(()).float() if s is not None else torch.zeros((), device=scalars[0].device)
-                            for s in scalars])
-        return vals.tolist()
+    # ---- step execution: eager, or one hipGraph replay -----------------------------------------
+    def enable_graph(self, flag: bool = True):
+        """Capture the whole training step (every kernel of both phases, the optimiser tail and the
+        RNG draws) into ONE hipGraph after a few eager warm-up steps and replay it per step: the
+        ~1.7 k launches of a step then cost one submission.  Used single-rank, without a writer,
+        with device-side noise; anything else silently runs eagerly."""
+        self._graph_on = bool(flag)
+        self._graph = None
+        return self
+
+    def _graph_ok(self):
+        import ops
+        return (getattr(self, "_graph_on", False) and self.writer is None and ddp.get() is None
+                and ops._noise["queue"] is None and ops._noise["mode"] == "device"
+                and plain_adam_hparams(self.optimizer_e) is not None and plain_adam_hparams(self.optimizer_d) is not None)
+
+    def _run(self, real: Tensor) -> Tensor:
+        """Runs ``_device_step`` eagerly or through the captured graph; returns the device stats vector."""
+        if not self._graph_ok():
+            return self._device_step(real)
+        key = (tuple(real.shape), real.dtype)
+        if getattr(self, "_graph", None) is None or self._graph_key != key:
+            self._graph_warm = getattr(self, "_graph_warm", 0) + 1
+            if self._graph_warm <= 3:
+                return self._device_step(real)          # eager warm-up: allocator, flat buffers, caches
+            from hipvae.functional import bump_weight_epoch
+            self._graph_in = real.clone()
+            bump_weight_epoch()                          # every weight gets re-packed inside the graph
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                self._graph_out = self._device_step(self._graph_in)
+            self._graph, self._graph_key = graph, key
+        from hipvae.functional import bump_weight_epoch
+        self._graph_in.copy_(real)
+        self._graph.replay()
+        bump_weight_epoch()                              # eager users after a replay must re-pack
+        return self._graph_out
 
     # ---- solvers/vae.py:89-136 ---------------------------------------------------------------
-    def train_step(self, batch: Tensor, cur_iter: int) -> dict:
-        if batch.dim() == 3:
-            batch = batch.unsqueeze(0)
-        real = batch.to(self.device)
+    def _device_step(self, real: Tensor) -> Tensor:
         self._set_trainable(True, True)
         mu, logvar, z, rec = self.model(real)
         loss_rec = self.compute_rec_loss(real, rec, reduction="mean", write=True)
@@ -124,7 +153,13 @@ class VAESolver:
         self._step("decoder")
         stats = torch.stack([loss.detach(), loss_kl.detach(), loss_rec.detach()])
         ddp.mean_scalars_(stats)
-        v_loss, v_kl, v_rec, v_norm = self._read(stats[0], stats[1], stats[2], norm)
+        return torch.cat([stats, norm if norm is not None else stats.new_zeros(1)])
+
+    def train_step(self, batch: Tensor, cur_iter: int) -> dict:
+        if batch.dim() == 3:
+            batch = batch.unsqueeze(0)
+        real = batch.to(self.device)
+        v_loss, v_kl, v_rec, v_norm = self._run(real).tolist()     # the step's only host read-back
         if v_loss != v_loss:
             raise RuntimeError
         if self.writer:
