@@ -22,6 +22,8 @@
 // half-wave (conflict free); operand fragments are double-buffered in registers across the
 // K-steps.  Global->register->LDS software pipeline with two LDS buffers and one barrier per
 // K-tile.  blockIdx -> tile mapping keeps tiles that share an im2col panel on one XCD.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace itcv {
@@ -250,15 +252,15 @@ struct WgradArgs {
 };
 
 // CB = channels per 128-wide N tile (16/32/64/128); TPB = 128/CB taps per tile
-template <int KS, int BM, int CB, int WM, int WN, bool UP2>
+template <int KS, int BM, int CB, int WM, int WN, bool UP2, int NBUF>
 __global__ __launch_bounds__(WM* WN * 64) void conv_wgrad_kernel(WgradArgs a) {
   constexpr int NT = WM * WN * 64, BK = 32, BN = 128, KK = KS * KS, P = KS / 2, TPB = BN / CB;
   constexpr int WTM = BM / WM, WTN = BN / WN, TM = WTM / 32, TN = WTN / 32;
   constexpr int PA = BM + 1, PB = BN + 1;  // odd pitch: transposing ds_write_b32 is conflict free
   constexpr int RP = NT / 32, AL = BM / RP, BL = BN / RP;
   static_assert(NT == 256 && RP == 8, "loader mapping assumes 256 threads");
-  __shared__ float As[2][BK * PA];
-  __shared__ float Bs[2][BK * PB];
+  __shared__ float As[NBUF][BK * PA];
+  __shared__ float Bs[NBUF][BK * PB];
 
   const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
   const int wm = wid / WN, wn = wid % WN, l31 = lane & 31, half = lane >> 5;
@@ -347,9 +349,15 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_wgrad_kernel(WgradArgs a) {
       const bool more = kt + 1 < kt1;
       if (more) load_tile(kt + 1);
       mfma_tile<BK, PA, PB, TM, TN>(&As[cur][half * PA + wm * WTM + l31], &Bs[cur][half * PB + wn * WTN + l31], acc);
-      if (more) store_tile(cur ^ 1);
-      __syncthreads();
-      cur ^= 1;
+      if (NBUF == 2) {
+        if (more) store_tile(cur ^ 1);
+        __syncthreads();
+        cur ^= 1;
+      } else {                      // one LDS buffer (half the LDS -> twice the resident blocks)
+        __syncthreads();
+        if (more) store_tile(0);
+        __syncthreads();
+      }
     }
   }
 
@@ -498,15 +506,29 @@ static void launch_fwd(const ConvArgs& a, int bm, int splits, int up2, hipStream
     launch_fwd_cfg<KS, 128, 128, 2, 2>(a, splits, up2, st);
 }
 
+static int wgrad_nbuf() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("ITCV_WGRAD_NBUF");
+    v = (e && e[0] == '2') ? 2 : 1;
+  }
+  return v;
+}
+
 template <int KS, int CB, bool UP2>
 static void launch_wgrad_bm(const WgradArgs& a, int bm, hipStream_t st) {
   dim3 grid(cdiv(a.splits, 8) * 8 * a.tiles);
-  if (bm == 32)
-    hipLaunchKernelGGL((conv_wgrad_kernel<KS, 32, CB, 1, 4, UP2>), grid, dim3(256), 0, st, a);
-  else if (bm == 64)
-    hipLaunchKernelGGL((conv_wgrad_kernel<KS, 64, CB, 1, 4, UP2>), grid, dim3(256), 0, st, a);
-  else
-    hipLaunchKernelGGL((conv_wgrad_kernel<KS, 128, CB, 2, 2, UP2>), grid, dim3(256), 0, st, a);
+  const bool two = wgrad_nbuf() == 2;
+  if (bm == 32) {
+    if (two) hipLaunchKernelGGL((conv_wgrad_kernel<KS, 32, CB, 1, 4, UP2, 2>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((conv_wgrad_kernel<KS, 32, CB, 1, 4, UP2, 1>), grid, dim3(256), 0, st, a);
+  } else if (bm == 64) {
+    if (two) hipLaunchKernelGGL((conv_wgrad_kernel<KS, 64, CB, 1, 4, UP2, 2>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((conv_wgrad_kernel<KS, 64, CB, 1, 4, UP2, 1>), grid, dim3(256), 0, st, a);
+  } else {
+    if (two) hipLaunchKernelGGL((conv_wgrad_kernel<KS, 128, CB, 2, 2, UP2, 2>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((conv_wgrad_kernel<KS, 128, CB, 2, 2, UP2, 1>), grid, dim3(256), 0, st, a);
+  }
 }
 template <int KS, bool UP2>
 static void launch_wgrad_cb(const WgradArgs& a, int bm, int cb, hipStream_t st) {
