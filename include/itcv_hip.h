@@ -51,6 +51,18 @@ int itcv_conv2d_pack_weight(const float* w, float* wp, int Co, int Ci, int KS, i
 size_t itcv_conv2d_fwd_workspace(int B, int Ci, int H, int W, int Co, int KS);
 int itcv_conv2d_fwd(const float* x, const float* wp, const float* bias, float* y, int B, int Ci,
                     int H, int W, int Co, int KS, int up2, void* ws, size_t ws_bytes, void* stream);
+/* Split-bf16 throughput variant of itcv_conv2d_fwd (forward and data-gradient): every fp32 operand
+ * is split into ns bf16 planes and the product is accumulated in fp32 on v_mfma_f32_32x32x16_bf16:
+ * ns = 2 ("bf16x3", 3 MFMAs per product, ~2^-16 relative per product), ns = 3 ("bf16x6", 6 MFMAs,
+ * fp32-class ~2^-23).  Supported for KS in {1,3}, Ci a multiple of 32, Co > 32 (see _supported);
+ * weights come pre-split from itcv_conv2d_pack_weight_bf16s. */
+int itcv_conv2d_bf16s_supported(int Ci, int Co, int KS);
+size_t itcv_conv2d_packed_weight_bytes_bf16s(int Co, int Ci, int KS, int for_dgrad, int ns);
+int itcv_conv2d_pack_weight_bf16s(const float* w, void* wp, int Co, int Ci, int KS, int for_dgrad, int ns,
+                                  void* stream);
+size_t itcv_conv2d_fwd_bf16s_workspace(int B, int Ci, int H, int W, int Co, int KS);
+int itcv_conv2d_fwd_bf16s(const float* x, const void* wp, const float* bias, float* y, int B, int Ci, int H,
+                          int W, int Co, int KS, int up2, int ns, void* ws, size_t ws_bytes, void* stream);
 /* dw[Co][Ci][KS][KS] (+)= sum_{b,h,w} dy[b][co][h][w] * x[b][ci][h+kh-p][w+kw-p]; `up2` as in _fwd
  * (x is the low-resolution [B][Ci][H/2][W/2] tensor, H/W are the dims of dy). */
 size_t itcv_conv2d_wgrad_workspace(int B, int Ci, int H, int W, int Co, int KS);

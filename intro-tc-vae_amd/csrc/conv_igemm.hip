@@ -237,6 +237,237 @@ __global__ void pack_weight_kernel(const float* __restrict__ w, float* __restric
   }
 }
 
+// ------------------------------------------------------------------------------ split-bf16 forward
+// Throughput variant of conv_fwd_kernel on the bf16 matrix cores (v_mfma_f32_32x32x16_bf16, 16x the
+// per-instruction work of the fp32 MFMA).  Every fp32 operand is split into NS bf16 planes
+// (x = x0 + x1 (+ x2), each plane the bf16 rounding of the remaining residual) and the product is
+// accumulated in fp32 over the plane pairs whose weight is above fp32 rounding:
+//   NS = 2 ("bf16x3"): x0y0 + x0y1 + x1y0            -> ~2^-16 relative per product
+//   NS = 3 ("bf16x6"): + x0y2 + x2y0 + x1y1           -> ~2^-23, i.e. fp32-class
+// Weights are split once at pack time; the gathered im2col operand is split on the way into LDS.
+// Same tap-major K order (32 channels of one tap per K-tile), same tile/XCD mapping and epilogue as
+// the fp32 kernel.  LDS holds 16-byte chunks [plane][k/8][row] so that every MFMA fragment is one
+// conflict-free ds_read_b128.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+struct ConvArgsB {
+  const float* x;
+  const u32x4* wp;
+  const float* bias;
+  float* y;
+  int B, Ci, H, W, Co;
+  int Mp, N;
+  int mt, nt;
+  int ktiles, ktiles_per_split, cpt;  // cpt = K-tiles per tap = Cip/32
+  uint32_t x_bytes;
+  size_t slab_stride;
+};
+
+template <int NS>
+__device__ __forceinline__ void split8(const float (&v)[8], u32x4 (&out)[NS]) {
+  bf16x8 pl[NS];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    float r = v[j];
+#pragma unroll
+    for (int p = 0; p < NS; ++p) {
+      const __bf16 b = (__bf16)r;
+      pl[p][j] = b;
+      r -= (float)b;
+    }
+  }
+#pragma unroll
+  for (int p = 0; p < NS; ++p) out[p] = __builtin_bit_cast(u32x4, pl[p]);
+}
+
+template <int KS, int BM, int BN, int WM, int WN, bool UP2, int NS>
+__global__ __launch_bounds__(WM* WN * 64) void conv_fwd_bf16s_kernel(ConvArgsB a) {
+  constexpr int NT = WM * WN * 64, BK = 32, KC = BK / 8, P = KS / 2;
+  constexpr int WTM = BM / WM, WTN = BN / WN, TM = WTM / 32, TN = WTN / 32;
+  static_assert(NT == 256 && (BN == 128 || BN == 256), "loader mapping");
+  __shared__ u32x4 As[NS * KC * BM];
+  __shared__ u32x4 Bs[NS * KC * BN];
+
+  const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
+  const int wm = wid / WN, wn = wid % WN, l31 = lane & 31, half = lane >> 5;
+  const int bid = blockIdx.x, xcd = bid & 7, q = bid >> 3;
+  const int tile_m = q % a.mt, tile_n = (q / a.mt) * 8 + xcd;
+  if (tile_n >= a.nt) return;
+  const int sk = blockIdx.y;
+  const int kt0 = sk * a.ktiles_per_split;
+  const int kt1 = min(a.ktiles, kt0 + a.ktiles_per_split);
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int H = a.H, W = a.W, HW = H * W;
+  const int Hs = UP2 ? H / 2 : H, Ws = UP2 ? W / 2 : W, HWs = Hs * Ws;
+
+  // ---- per-thread im2col column -------------------------------------------------------------
+  constexpr int BROWS = NT / BN;            // k groups of the tile split over thread rows (2 or 1)
+  constexpr int RPT = BK / BROWS;           // k rows per thread: 16 or 32
+  const int nl = t % BN;
+  const int kg = __builtin_amdgcn_readfirstlane(t / BN);   // this thread's rows: kg*RPT .. kg*RPT+RPT-1
+  const int n = n0 + nl;
+  const bool nvalid = n < a.N;
+  int bi = 0, h = 0, w = 0;
+  if (nvalid) {
+    bi = n / HW;
+    const int hw = n - bi * HW;
+    h = hw / W;
+    w = hw - h * W;
+  }
+  uint32_t tapmask = 0;
+#pragma unroll
+  for (int tap = 0; tap < KS * KS; ++tap) {
+    const int dh = tap / KS - P, dw = tap % KS - P;
+    if (nvalid && (unsigned)(h + dh) < (unsigned)H && (unsigned)(w + dw) < (unsigned)W) tapmask |= 1u << tap;
+  }
+  const int tb = bi * a.Ci * HWs + (UP2 ? 0 : h * W + w);
+  const __amdgpu_buffer_rsrc_t rx = make_rsrc(a.x, a.x_bytes);
+  const uint32_t hw4 = (uint32_t)HWs * 4u, row0_4 = (uint32_t)(kg * RPT) * hw4;
+
+  constexpr int AV = NS * KC * BM, AL = AV / NT;   // 16-byte chunks of the A tile per thread
+  static_assert(AV % NT == 0, "A tile chunks must divide evenly");
+  u32x4 areg[AL];
+  float breg[RPT];
+
+  auto load_tile = [&](int kt, int tap, int cib) {
+    // packed weights: [kt][plane][kc][Mp] chunks; this tile's chunks for rows m0..m0+BM-1
+    const u32x4* wt = a.wp + (size_t)kt * NS * KC * a.Mp;
+#pragma unroll
+    for (int i = 0; i < AL; ++i) {
+      const int idx = t + i * NT, pk = idx / BM, ml = idx - pk * BM;   // pk = plane*KC + kc
+      areg[i] = wt[(size_t)pk * a.Mp + m0 + ml];
+    }
+    const int dh = tap / KS - P, dw = tap - (tap / KS) * KS - P;
+    const bool valid = (tapmask >> tap) & 1u;
+    int off;
+    if (UP2)
+      off = tb + ((h + dh) >> 1) * Ws + ((w + dw) >> 1) + cib * BK * HWs;
+    else
+      off = tb + dh * W + dw + cib * BK * HWs;
+    const uint32_t voff = valid ? (uint32_t)off * 4u : kOobBase;
+#pragma unroll
+    for (int i = 0; i < RPT; ++i) breg[i] = buf_load_s(rx, voff, row0_4 + (uint32_t)i * hw4);
+  };
+  auto store_tile = [&]() {
+#pragma unroll
+    for (int i = 0; i < AL; ++i) As[t + i * NT] = areg[i];
+#pragma unroll
+    for (int c = 0; c < RPT / 8; ++c) {
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = breg[c * 8 + j];
+      u32x4 pl[NS];
+      split8<NS>(v, pl);
+      const int kc = kg * (RPT / 8) + c;
+#pragma unroll
+      for (int p = 0; p < NS; ++p) Bs[(p * KC + kc) * BN + nl] = pl[p];
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  auto mfma_step = [&]() {
+#pragma unroll
+    for (int ks = 0; ks < BK / 16; ++ks) {
+      const int kc = ks * 2 + half;
+      bf16x8 af[NS][TM], bfr[NS][TN];
+#pragma unroll
+      for (int p = 0; p < NS; ++p) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+          af[p][i] = __builtin_bit_cast(bf16x8, As[(p * KC + kc) * BM + wm * WTM + i * 32 + l31]);
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          bfr[p][j] = __builtin_bit_cast(bf16x8, Bs[(p * KC + kc) * BN + wn * WTN + j * 32 + l31]);
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          f32x16 c = acc[i][j];
+          if (NS == 3) {   // smallest terms first
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][i], bfr[1][j], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bfr[2][j], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2][i], bfr[0][j], c, 0, 0, 0);
+          }
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bfr[1][j], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][i], bfr[0][j], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bfr[0][j], c, 0, 0, 0);
+          acc[i][j] = c;
+        }
+    }
+  };
+
+  if (kt0 < kt1) {
+    int tap = kt0 / a.cpt, cib = kt0 - tap * a.cpt;
+    load_tile(kt0, tap, cib);
+    store_tile();
+    __syncthreads();
+    for (int kt = kt0; kt < kt1; ++kt) {
+      const bool more = kt + 1 < kt1;
+      if (++cib == a.cpt) cib = 0, ++tap;
+      if (more) load_tile(kt + 1, tap, cib);
+      mfma_step();
+      __syncthreads();
+      if (more) store_tile();
+      __syncthreads();
+    }
+  }
+
+  float* out = a.y + (size_t)sk * a.slab_stride;
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int nn = n0 + wn * WTN + j * 32 + l31;
+    if (nn >= a.N) continue;
+    const int b2 = nn / HW, hw2 = nn - b2 * HW;
+    const size_t base = (size_t)b2 * a.Co * HW + hw2;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (m < a.Co) {
+          float v = acc[i][j][r];
+          if (a.bias) v += a.bias[m];
+          out[base + (size_t)m * HW] = v;
+        }
+      }
+    }
+  }
+}
+
+// wp[kt = tap*cpt + cib][plane][kc][Mp] 16-byte chunks of 8 bf16: channels cib*32 + kc*8 + j
+template <int NS>
+__global__ void pack_weight_bf16s_kernel(const float* __restrict__ w, u32x4* __restrict__ wp, int Co, int Ci, int KK,
+                                         int for_dgrad, int C, int M, int cpt, int Mp) {
+  const size_t total = (size_t)KK * cpt * 4 * Mp;   // one thread per (kt, kc, m)
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int m = (int)(i % Mp);
+    const size_t r = i / Mp;
+    const int kc = (int)(r & 3), kt = (int)(r >> 2);
+    const int tap = kt / cpt, cib = kt - tap * cpt;
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int c = cib * 32 + kc * 8 + j;
+      v[j] = (c < C && m < M) ? (for_dgrad ? w[((size_t)c * Ci + m) * KK + (KK - 1 - tap)]
+                                           : w[((size_t)m * Ci + c) * KK + tap])
+                              : 0.f;
+    }
+    u32x4 pl[NS];
+    split8<NS>(v, pl);
+#pragma unroll
+    for (int p = 0; p < NS; ++p) wp[(((size_t)kt * NS + p) * 4 + kc) * Mp + m] = pl[p];
+  }
+}
+
 // ------------------------------------------------------------------------------ wgrad
 struct WgradArgs {
   const float* x;
@@ -549,6 +780,45 @@ static void launch_wgrad(const WgradArgs& a, int bm, int cb, int up2, hipStream_
     launch_wgrad_cb<KS, false>(a, bm, cb, st);
 }
 
+static inline int pad32(int c) { return (c + 31) & ~31; }
+
+struct FwdPlanB {
+  int bm, bn, mt, nt, cip, ktiles, splits, kps;
+};
+static FwdPlanB plan_fwd_b(int B, int Ci, int H, int W, int Co, int KS) {
+  FwdPlanB p;
+  const long long N = (long long)B * H * W;
+  p.bm = Co <= 64 ? 64 : 128;
+  p.bn = p.bm == 128 ? 128 : 256;
+  p.mt = cdiv(Co, p.bm);
+  p.nt = (int)((N + p.bn - 1) / p.bn);
+  p.cip = pad32(Ci);
+  p.ktiles = KS * KS * (p.cip / 32);
+  const int tiles = p.mt * p.nt;
+  int splits = 1;
+  if (tiles < 192 && p.ktiles >= 8) {
+    splits = cdiv(512, tiles);
+    if (splits > p.ktiles / 4) splits = p.ktiles / 4;
+    if (splits > 64) splits = 64;
+    if (splits < 1) splits = 1;
+  }
+  p.kps = cdiv(p.ktiles, splits);
+  p.splits = cdiv(p.ktiles, p.kps);
+  return p;
+}
+
+template <int KS, int NS>
+static void launch_fwd_b(const ConvArgsB& a, int bm, int splits, int up2, hipStream_t st) {
+  dim3 grid(cdiv(a.nt, 8) * 8 * a.mt, splits), block(256);
+  if (bm == 64) {
+    if (up2) hipLaunchKernelGGL((conv_fwd_bf16s_kernel<KS, 64, 256, 1, 4, true, NS>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((conv_fwd_bf16s_kernel<KS, 64, 256, 1, 4, false, NS>), grid, block, 0, st, a);
+  } else {
+    if (up2) hipLaunchKernelGGL((conv_fwd_bf16s_kernel<KS, 128, 128, 2, 2, true, NS>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((conv_fwd_bf16s_kernel<KS, 128, 128, 2, 2, false, NS>), grid, block, 0, st, a);
+  }
+}
+
 static int check_dims(const char* name, int B, int Ci, int H, int W, int Co, int KS) {
   if (!(KS == 1 || KS == 3 || KS == 5)) return fail("%s: kernel size must be 1, 3 or 5 (got %lld)", name, KS);
   if (B <= 0 || Ci <= 0 || H <= 0 || W <= 0 || Co <= 0) return fail("%s: empty or negative dimension", name);
@@ -632,6 +902,82 @@ int itcv_conv2d_fwd(const float* x, const float* wp, const float* bias, float* y
     hipLaunchKernelGGL(splitk_reduce_fwd, dim3(blocks), dim3(256), 0, st, static_cast<const float*>(ws), bias, y,
                        out_elems, out_elems, p.splits, H * W, Co);
     ITCV_CHECK_LAUNCH("itcv_conv2d_fwd(reduce)");
+  }
+  return 0;
+}
+
+// ---- split-bf16 forward / data-gradient (throughput mode) -----------------------------------
+int itcv_conv2d_bf16s_supported(int Ci, int Co, int KS) {
+  return (KS == 1 || KS == 3) && Ci >= 32 && Ci % 32 == 0 && Co >= 33;
+}
+
+size_t itcv_conv2d_packed_weight_bytes_bf16s(int Co, int Ci, int KS, int for_dgrad, int ns) {
+  const int M = for_dgrad ? Ci : Co, C = for_dgrad ? Co : Ci;
+  const int bm = M <= 64 ? 64 : 128;
+  return (size_t)KS * KS * (pad32(C) / 32) * ns * 4 * (cdiv(M, bm) * bm) * 16;
+}
+
+int itcv_conv2d_pack_weight_bf16s(const float* w, void* wp, int Co, int Ci, int KS, int for_dgrad, int ns,
+                                  void* stream) {
+  ITCV_REQUIRE(w && wp && Co > 0 && Ci > 0 && (KS == 1 || KS == 3) && (ns == 2 || ns == 3),
+               "itcv_conv2d_pack_weight_bf16s");
+  const int M = for_dgrad ? Ci : Co, C = for_dgrad ? Co : Ci;
+  const int bm = M <= 64 ? 64 : 128, Mp = cdiv(M, bm) * bm, cpt = pad32(C) / 32;
+  const size_t total = (size_t)KS * KS * cpt * 4 * Mp;
+  const int blocks = (int)(cdivz(total, 256) < 4096 ? cdivz(total, 256) : 4096);
+  if (ns == 2)
+    hipLaunchKernelGGL(pack_weight_bf16s_kernel<2>, dim3(blocks), dim3(256), 0, S(stream), w, static_cast<u32x4*>(wp),
+                       Co, Ci, KS * KS, for_dgrad, C, M, cpt, Mp);
+  else
+    hipLaunchKernelGGL(pack_weight_bf16s_kernel<3>, dim3(blocks), dim3(256), 0, S(stream), w, static_cast<u32x4*>(wp),
+                       Co, Ci, KS * KS, for_dgrad, C, M, cpt, Mp);
+  ITCV_CHECK_LAUNCH("itcv_conv2d_pack_weight_bf16s");
+  return 0;
+}
+
+size_t itcv_conv2d_fwd_bf16s_workspace(int B, int Ci, int H, int W, int Co, int KS) {
+  if (B <= 0 || Ci <= 0 || H <= 0 || W <= 0 || Co <= 0) return 0;
+  const FwdPlanB p = plan_fwd_b(B, Ci, H, W, Co, KS);
+  return p.splits > 1 ? (size_t)p.splits * B * Co * H * W * sizeof(float) : 0;
+}
+
+int itcv_conv2d_fwd_bf16s(const float* x, const void* wp, const float* bias, float* y, int B, int Ci, int H, int W,
+                          int Co, int KS, int up2, int ns, void* ws, size_t ws_bytes, void* stream) {
+  if (int e = check_dims("itcv_conv2d_fwd_bf16s", B, Ci, H, W, Co, KS)) return e;
+  ITCV_REQUIRE(x && wp && y && (ns == 2 || ns == 3), "itcv_conv2d_fwd_bf16s");
+  if (!itcv_conv2d_bf16s_supported(Ci, Co, KS))
+    return fail("%s: shape not supported by the split-bf16 kernel (Ci %% 32, Co > 32, KS 1/3)", "itcv_conv2d_fwd_bf16s");
+  if (up2) ITCV_REQUIRE(H % 2 == 0 && W % 2 == 0, "itcv_conv2d_fwd_bf16s(up2)");
+  const FwdPlanB p = plan_fwd_b(B, Ci, H, W, Co, KS);
+  const size_t out_elems = (size_t)B * Co * H * W;
+  if (p.splits > 1 && (!ws || ws_bytes < (size_t)p.splits * out_elems * sizeof(float)))
+    return fail("%s: workspace too small (need %lld bytes)", "itcv_conv2d_fwd_bf16s",
+                (long long)((size_t)p.splits * out_elems * sizeof(float)));
+  ConvArgsB a;
+  a.x = x;
+  a.wp = static_cast<const u32x4*>(wp);
+  a.bias = p.splits > 1 ? nullptr : bias;
+  a.y = p.splits > 1 ? static_cast<float*>(ws) : y;
+  a.B = B, a.Ci = Ci, a.H = H, a.W = W, a.Co = Co;
+  a.Mp = p.mt * p.bm;
+  a.N = B * H * W;
+  a.mt = p.mt, a.nt = p.nt, a.ktiles = p.ktiles, a.ktiles_per_split = p.kps, a.cpt = p.cip / 32;
+  a.x_bytes = (uint32_t)((size_t)B * Ci * (up2 ? (H / 2) * (W / 2) : H * W) * sizeof(float));
+  a.slab_stride = p.splits > 1 ? out_elems : 0;
+  hipStream_t st = S(stream);
+  if (KS == 1) {
+    if (ns == 2) launch_fwd_b<1, 2>(a, p.bm, p.splits, up2, st);
+    else launch_fwd_b<1, 3>(a, p.bm, p.splits, up2, st);
+  } else {
+    if (ns == 2) launch_fwd_b<3, 2>(a, p.bm, p.splits, up2, st);
+    else launch_fwd_b<3, 3>(a, p.bm, p.splits, up2, st);
+  }
+  ITCV_CHECK_LAUNCH("itcv_conv2d_fwd_bf16s");
+  if (p.splits > 1) {
+    const int blocks = (int)(cdivz(out_elems, 256) < 2048 ? cdivz(out_elems, 256) : 2048);
+    hipLaunchKernelGGL(splitk_reduce_fwd, dim3(blocks), dim3(256), 0, st, static_cast<const float*>(ws), bias, y,
+                       out_elems, out_elems, p.splits, H * W, Co);
+    ITCV_CHECK_LAUNCH("itcv_conv2d_fwd_bf16s(reduce)");
   }
   return 0;
 }

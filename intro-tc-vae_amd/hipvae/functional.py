@@ -64,7 +64,29 @@ def bump_weight_epoch():
     _WEIGHT_EPOCH[0] += 1
 
 
-def packed_weight(weight, w4, for_dgrad):
+import os as _os
+
+_NS = {"fp32": 0, "bf16x3": 2, "bf16x6": 3}
+_CONV_MATH = [_os.environ.get("ITCV_CONV_MATH", "fp32")]
+assert _CONV_MATH[0] in _NS, "ITCV_CONV_MATH must be one of fp32 / bf16x3 / bf16x6"
+
+
+def set_conv_math(mode):
+    """Arithmetic of the conv/linear forward and data-gradient GEMMs:
+    'fp32'   exact fp32 MFMA (v_mfma_f32_32x32x2_f32) -- the parity path and the default;
+    'bf16x6' operands split into 3 bf16 planes, 6 bf16 MFMAs per product, fp32 accumulate: fp32-class
+             accuracy (~2^-23 per product) at 2.7x the matrix-core rate;
+    'bf16x3' 2 planes / 3 MFMAs: ~2^-16 per product at 5.3x the matrix-core rate.
+    Layers the split kernel does not cover (3-channel stem/predict, KS=5) stay on the fp32 kernel."""
+    assert mode in _NS, mode
+    _CONV_MATH[0] = mode
+
+
+def conv_math():
+    return _CONV_MATH[0]
+
+
+def packed_weight(weight, w4, for_dgrad, ns=0):
     """Packed operand of ``weight`` (viewed as ``w4`` [Co,Ci,KS,KS]), cached until the weight changes:
     the frozen half of the model is packed once per phase instead of once per network pass."""
     key = (weight.data_ptr(), weight._version, _WEIGHT_EPOCH[0])
@@ -74,10 +96,44 @@ def packed_weight(weight, w4, for_dgrad):
         weakref.finalize(weight, _PACK_CACHE.pop, id(weight), None)
     elif ent[0] != key:
         ent[0], ent[1] = key, {}
-    wp = ent[1].get(for_dgrad)
+    wp = ent[1].get((for_dgrad, ns))
     if wp is None:
-        wp = ent[1][for_dgrad] = pack_weight(w4, for_dgrad)
+        wp = ent[1][(for_dgrad, ns)] = pack_weight(w4, for_dgrad) if ns == 0 else pack_weight_bf16s(w4, for_dgrad, ns)
     return wp
+
+
+def pack_weight_bf16s(w4, for_dgrad, ns):
+    co, ci, ks = w4.shape[0], w4.shape[1], w4.shape[2]
+    nbytes = lib.itcv_conv2d_packed_weight_bytes_bf16s(co, ci, ks, int(for_dgrad), ns)
+    wp = torch.empty(nbytes // 4, dtype=torch.int32, device=w4.device)
+    call("itcv_conv2d_pack_weight_bf16s", ptr(w4), ptr(wp), co, ci, ks, int(for_dgrad), ns, stream())
+    return wp
+
+
+def conv_apply(x, weight, w4, for_dgrad, bias, B, Ci, H, W, Co, KS, up2):
+    """Forward-type conv GEMM (forward, or data-gradient with the roles of Ci/Co swapped by the caller)
+    on the kernel selected by set_conv_math()."""
+    ns = _NS[_CONV_MATH[0]]
+    if ns and lib.itcv_conv2d_bf16s_supported(Ci, Co, KS):
+        wp = packed_weight(weight, w4, for_dgrad, ns)
+        y = torch.empty((B, Co, H, W), dtype=F32, device=x.device)
+        nws = lib.itcv_conv2d_fwd_bf16s_workspace(B, Ci, H, W, Co, KS)
+        ws = _ws(nws, x.device) if nws else None
+
+        def launch():
+            call("itcv_conv2d_fwd_bf16s", ptr(x), ptr(wp), ptr(bias), ptr(y), B, Ci, H, W, Co, KS, int(up2), ns,
+                 ptr(ws), nws, stream())
+            return y
+        if LaunchProfile.active is None:
+            return launch()
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        launch()
+        e.record()
+        LaunchProfile.active.append((f"conv_fwd_bf16s_kernel<KS={KS},BM={64 if Co <= 64 else 128},up2={int(up2)},"
+                                     f"NS={ns}>", 2.0 * B * H * W * Co * Ci * KS * KS, s, e))
+        return y
+    return conv_fwd_raw(x, packed_weight(weight, w4, for_dgrad), bias, B, Ci, H, W, Co, KS, up2)
 
 
 def pack_weight(w4, for_dgrad):
@@ -166,8 +222,7 @@ class Conv2dFn(Function):
         B, Ci, Hs, Ws = x.shape
         Co, KS = weight.shape[0], weight.shape[2]
         H, W = (Hs * 2, Ws * 2) if up2 else (Hs, Ws)
-        y = conv_fwd_raw(x, packed_weight(weight, weight, 0), None if bias is None else _f32c(bias), B, Ci, H, W, Co,
-                         KS, up2)
+        y = conv_apply(x, weight, weight, 0, None if bias is None else _f32c(bias), B, Ci, H, W, Co, KS, up2)
         ctx.save_for_backward(x, weight, bias)
         ctx.cfg = (B, Ci, H, W, Co, KS, up2, bias is not None)
         return y
@@ -180,7 +235,7 @@ class Conv2dFn(Function):
         dy = _f32c(dy)
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            dx = conv_fwd_raw(dy, packed_weight(weight, weight, 1), None, B, Co, H, W, Ci, KS, False)
+            dx = conv_apply(dy, weight, weight, 1, None, B, Co, H, W, Ci, KS, False)
             if up2:
                 lo = torch.empty((B, Ci, H // 2, W // 2), dtype=F32, device=dy.device)
                 call("itcv_upsample2_bwd", ptr(dx), ptr(lo), B * Ci, H // 2, W // 2, stream())
@@ -205,8 +260,7 @@ class LinearFn(Function):
         B, Ci = x.shape
         Co = weight.shape[0]
         w4 = weight.view(Co, Ci, 1, 1)
-        y = conv_fwd_raw(x, packed_weight(weight, w4, 0), None if bias is None else _f32c(bias), B, Ci, 1, 1, Co, 1,
-                         False)
+        y = conv_apply(x, weight, w4, 0, None if bias is None else _f32c(bias), B, Ci, 1, 1, Co, 1, False)
         ctx.save_for_backward(x, weight, bias)
         ctx.cfg = (B, Ci, Co, bias is not None)
         return y.view(B, Co)
@@ -219,8 +273,7 @@ class LinearFn(Function):
         dy = _f32c(dy)
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            dx = conv_fwd_raw(dy, packed_weight(weight, weight.view(Co, Ci, 1, 1), 1), None, B, Co, 1, 1, Ci, 1,
-                              False).view(B, Ci)
+            dx = conv_apply(dy, weight, weight.view(Co, Ci, 1, 1), 1, None, B, Co, 1, 1, Ci, 1, False).view(B, Ci)
         if ctx.needs_input_grad[1]:
             tgt = _grad_target(weight)
             if tgt is not None:

@@ -43,8 +43,17 @@ def main():
         tf = timeit(lambda: HF.conv_fwd_raw(x, wp, None, B, Ci, S, S, Co, KS, False))
         td = timeit(lambda: HF.conv_fwd_raw(dy, wpt, None, B, Co, S, S, Ci, KS, False))
         tw = timeit(lambda: HF.conv_wgrad_raw(x, dy, B, Ci, S, S, Co, KS, False))
+        extra = ""
+        if HF.lib.itcv_conv2d_bf16s_supported(Ci, Co, KS) and HF.lib.itcv_conv2d_bf16s_supported(Co, Ci, KS):
+            ref = HF.conv_fwd_raw(x, wp, None, B, Ci, S, S, Co, KS, False)
+            for mode in ("bf16x3", "bf16x6"):
+                HF.set_conv_math(mode)
+                t3 = timeit(lambda: HF.conv_apply(x, w, w, 0, None, B, Ci, S, S, Co, KS, False))
+                err = float((HF.conv_apply(x, w, w, 0, None, B, Ci, S, S, Co, KS, False) - ref).abs().max() / ref.abs().max())
+                extra += f" | {mode} {t3*1e3:6.3f} ms {gf/t3*1e-3:6.1f} TFeq err {err:.1e}"
+            HF.set_conv_math("fp32")
         print(f"{Ci:4d}->{Co:4d}@{S:3d} k{KS} B{B:3d} {gf:7.2f} | {tf*1e3:8.3f} {gf/tf*1e-3:6.1f} | "
-              f"{td*1e3:8.3f} {gf/td*1e-3:6.1f} | {tw*1e3:8.3f} {gf/tw*1e-3:6.1f}")
+              f"{td*1e3:8.3f} {gf/td*1e-3:6.1f} | {tw*1e3:8.3f} {gf/tw*1e-3:6.1f}" + extra)
         tot[0] += gf; tot[1] += tf; tot[2] += td; tot[3] += tw
     print(f"{'sum':>22} {tot[0]:7.2f} | {tot[1]*1e3:8.3f} {tot[0]/tot[1]*1e-3:6.1f} | {tot[2]*1e3:8.3f} "
           f"{tot[0]/tot[2]*1e-3:6.1f} | {tot[3]*1e3:8.3f} {tot[0]/tot[3]*1e-3:6.1f}")
