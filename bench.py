@@ -38,6 +38,7 @@ CFG = dict(cdim=3, zdim=128, channels=(64, 128, 256, 512), image_size=64)
 B_PER_GPU = 64
 HP = dict(beta_kl=0.5, beta_rec=0.75, beta_neg=512.0, gamma_r=1e-8, clip=100.0, lr=2e-4, dataset=10000)
 PEAK_F32_MFMA_TFLOPS = 157.3
+PEAK_BF16_MFMA_TFLOPS = 2500.0       # dense; a split product costs 3 (bf16x3) or 6 (bf16x6) bf16 MFMA products
 # 13*Fe + 19*Fd = 48.237 GFLOP per image per intro-tc step (2*MAC, conv+linear)
 STEP_GFLOP_PER_IMAGE = 48.237
 
@@ -106,6 +107,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sync-bn", action="store_true", help="per-rank BatchNorm statistics (throughput mode)")
+    ap.add_argument("--math", choices=["bf16x3", "bf16x6", "fp32"], default="bf16x3",
+                    help="conv GEMM arithmetic: bf16x3 = use_amp=True (the reference's config default), split-bf16 "
+                         "MFMA with fp32 accumulate; bf16x6 = fp32-class 3-way split; fp32 = exact fp32 MFMA")
     ap.add_argument("--no-graph", action="store_true", help="time eager launches instead of hipGraph replays (N=1)")
     args = ap.parse_args()
 
@@ -136,7 +140,8 @@ def main():
     opt_e = torch.optim.Adam(model.encoder.parameters(), lr=HP["lr"])
     opt_d = torch.optim.Adam(model.decoder.parameters(), lr=HP["lr"])
     solver = IntroTCSovler(_DS(), model, B_PER_GPU, opt_e, opt_d, "mse", HP["beta_kl"], HP["beta_rec"],
-                           HP["beta_neg"], HP["gamma_r"], dev, False, None, clip=HP["clip"])
+                           HP["beta_neg"], HP["gamma_r"], dev, args.math != "fp32", None, clip=HP["clip"])
+    solver.conv_math = args.math
     g = torch.Generator().manual_seed(1000 + rank)
     batches = [torch.rand(B_PER_GPU, 3, 64, 64, generator=g).to(dev) for _ in range(4)]   # resident in HBM
 
@@ -193,9 +198,14 @@ def main():
     conv_flop = sum(b[1] for b in buckets.values())
     dom_label, dom = max(buckets.items(), key=lambda kv: kv[1][2])
     achieved = dom[1] / dom[2] * 1e-12
+    if "bf16s" in dom_label:
+        products = 3 if "NS=2" in dom_label else 6
+        peak, peak_note = PEAK_BF16_MFMA_TFLOPS / products, f"2500 TFLOP/s dense bf16 MFMA / {products} bf16 products per fp32 product"
+    else:
+        peak, peak_note = PEAK_F32_MFMA_TFLOPS, "dense fp32 MFMA"
     roofline = {
-        "bound": "mfma", "kernel": dom_label, "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS,
-        "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+        "bound": "mfma", "kernel": dom_label, "achieved": round(achieved, 2), "peak": round(peak, 1),
+        "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": None, "peak_note": peak_note,
         "launches_per_step": dom[0] / args.steps, "avg_launch_us": round(dom[2] / dom[0] * 1e6, 2),
         "algorithmic_gflop_per_launch": round(dom[1] / dom[0] * 1e-9, 3),
         "all_conv_kernels": {"achieved": round(conv_flop / conv_time * 1e-12, 2),
@@ -209,7 +219,10 @@ def main():
     out = {
         "metric": "images/sec (64x64x3, z=128, bs=64) intro-TC step", "value": round(value, 2), "unit": "images/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": {"fp32": "f32", "bf16x3": "f32 in/out/accumulate, conv products on split-bf16 MFMA (bf16x3)",
+                  "bf16x6": "f32 in/out/accumulate, conv products on split-bf16 MFMA (bf16x6, fp32-class)"}[args.math],
+        "data": "synthetic",
         "config": {"workload": "c2: IntroTCSovler.train_step, conv arch, 64x64x3, z_dim=128, channels (64,128,256,512), "
                                f"batch {B_PER_GPU}/GPU, Adam lr 2e-4, clip 100, N=10000",
                    "global_batch": B_PER_GPU * world, "parallelism": f"dp{world}" if world > 1 else "single",
@@ -217,7 +230,7 @@ def main():
         "execution": "hipGraph replay (whole step = one graph)" if use_graph else "eager launches",
         "eager_ms_per_step": round(eager_elapsed / args.steps * 1e3, 3),
         "step_tflop": round(STEP_GFLOP_PER_IMAGE * B_PER_GPU * world * 1e-3, 3),
-        "whole_step_mfma_frac": round(value * STEP_GFLOP_PER_IMAGE * 1e-3 / (PEAK_F32_MFMA_TFLOPS * world), 4),
+        "whole_step_tflops": round(value * STEP_GFLOP_PER_IMAGE * 1e-3 / world, 2),
         "last_step": last,
         "roofline": roofline,
     }

@@ -86,6 +86,20 @@ def conv_math():
     return _CONV_MATH[0]
 
 
+@contextlib.contextmanager
+def conv_math_scope(mode):
+    """Temporarily select the conv arithmetic (used by the solvers: ``use_amp`` picks the mode)."""
+    if mode is None:
+        yield
+        return
+    assert mode in _NS, mode
+    prev, _CONV_MATH[0] = _CONV_MATH[0], mode
+    try:
+        yield
+    finally:
+        _CONV_MATH[0] = prev
+
+
 def packed_weight(weight, w4, for_dgrad, ns=0):
     """Packed operand of ``weight`` (viewed as ``w4`` [Co,Ci,KS,KS]), cached until the weight changes:
     the frozen half of the model is packed once per phase instead of once per network pass."""

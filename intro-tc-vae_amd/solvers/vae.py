@@ -10,7 +10,7 @@ import torch
 from torch import Tensor
 
 from hipvae import ddp
-from hipvae.functional import direct_grad_accumulation
+from hipvae.functional import conv_math_scope, direct_grad_accumulation
 from hipvae.flat import FlatGroup, clip_grad_norm, plain_adam_hparams
 from ops import kl_divergence, reconstruction_loss
 from utils import SingletonWriter
@@ -38,7 +38,14 @@ class VAESolver:
         self.optimizer_e, self.optimizer_d = optimizer_e, optimizer_d
         self.beta_kl, self.beta_rec = beta_kl, beta_rec
         self.device = device
-        self.use_amp, self.grad_scaler = use_amp, grad_scaler      # stored, unused (as in the reference)
+        # The reference stores use_amp / grad_scaler and never uses them (no autocast anywhere).  Here
+        # use_amp selects the arithmetic of the conv GEMMs: True -> split-bf16 matrix cores with fp32
+        # accumulate ("bf16x3": fp32 in/out, ~2^-16 per product, all parity tests hold), False -> exact
+        # fp32 MFMA.  ``conv_math`` may be set to "fp32" / "bf16x6" / "bf16x3" directly; the ITCV_CONV_MATH
+        # environment variable overrides both.
+        self.use_amp, self.grad_scaler = use_amp, grad_scaler
+        import os as _os
+        self.conv_math = _os.environ.get("ITCV_CONV_MATH") or ("bf16x3" if use_amp else "fp32")
         self.writer, self.test_iter, self.clip = writer, test_iter, clip
         self.recon_loss_type = recon_loss_type
         self.scale = 1 / (self.model.cdim * self.model.encoder.image_size ** 2)   # solvers/vae.py:61
@@ -119,9 +126,13 @@ class VAESolver:
 
     def _run(self, real: Tensor) -> Tensor:
         """Runs ``_device_step`` eagerly or through the captured graph; returns the device stats vector."""
+        with conv_math_scope(self.conv_math):
+            return self._run_scoped(real)
+
+    def _run_scoped(self, real: Tensor) -> Tensor:
         if not self._graph_ok():
             return self._device_step(real)
-        key = (tuple(real.shape), real.dtype)
+        key = (tuple(real.shape), real.dtype, self.conv_math)
         if getattr(self, "_graph", None) is None or self._graph_key != key:
             self._graph_warm = getattr(self, "_graph_warm", 0) + 1
             if self._graph_warm <= 3:

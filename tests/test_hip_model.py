@@ -85,7 +85,10 @@ class _DS:
         return self.n
 
 
-def make_solver(name, model, hp, loss_type="mse"):
+MATH_MODES = ["fp32", "bf16x6", "bf16x3"]
+
+
+def make_solver(name, model, hp, loss_type="mse", math="fp32"):
     from solvers import IntroSolver, VAESolver
     from solvers.intro_tc import IntroTCSovler
     from solvers.tc import TCSovler
@@ -97,7 +100,9 @@ def make_solver(name, model, hp, loss_type="mse"):
               grad_scaler=None, writer=None, test_iter=1000, clip=hp[4])
     if name.startswith("intro"):
         kw.update(beta_neg=hp[2], gamma_r=hp[3])
-    return cls(**kw)
+    solver = cls(**kw)
+    solver.conv_math = math
+    return solver
 
 
 def run_golden_steps(fname, arch, loss_type, names, nsteps):
@@ -153,6 +158,16 @@ def test_steps_conv_golden():
     run_golden_steps("steps_conv.npz", "conv", "mse", ("vae", "tc", "intro", "intro_tc"), 2)
 
 
+def test_use_amp_selects_split_bf16():
+    """use_amp=True (the reference config's default, inert there) maps to the bf16x3 conv arithmetic."""
+    import models
+    from solvers.intro_tc import IntroTCSovler
+    m = models.SoftIntroVAE(arch="conv", **TINY).to(dev())
+    mk = lambda amp: IntroTCSovler(_DS(10), m, 4, torch.optim.Adam(m.encoder.parameters()),  # noqa: E731
+                                   torch.optim.Adam(m.decoder.parameters()), "mse", 1.0, 1.0, 1.0, 1e-8, dev(), amp, None)
+    assert mk(True).conv_math == "bf16x3" and mk(False).conv_math == "fp32"
+
+
 def test_steps_res_golden():
     run_golden_steps("steps_res.npz", "res", "mse", ("vae", "tc", "intro", "intro_tc"), 1)
 
@@ -161,9 +176,12 @@ def test_steps_bce_golden():
     run_golden_steps("steps_conv_bce.npz", "conv", "bce", ("vae", "intro_tc"), 1)
 
 
-def test_intro_tc_step_64x64_vs_oracle():
+@pytest.mark.parametrize("math", MATH_MODES)
+def test_intro_tc_step_64x64_vs_oracle(math):
     """The benchmark shape at a batch the CPU oracle finishes in seconds (64x64x3, z=128,
-    channels (64,128,256,512), B=8): one intro-TC step, HIP vs oracle on identical weights / draws."""
+    channels (64,128,256,512), B=8): one intro-TC step, HIP vs oracle on identical weights / draws,
+    in every conv arithmetic (exact fp32 MFMA, bf16x6, bf16x3 = the benchmark's use_amp mode).
+    Bar: every returned scalar within 1e-4 relative."""
     import models
     from oracle.network import Net
     from oracle.steps import Trainer
@@ -173,7 +191,7 @@ def test_intro_tc_step_64x64_vs_oracle():
     sd = {k: v.clone() for k, v in model.state_dict().items()}
     model = model.to(dev()).train()
     hp = [0.5, 0.75, 512.0, 1e-8, 100.0, 2e-4, 10000]
-    solver = make_solver("intro_tc", model, hp)
+    solver = make_solver("intro_tc", model, hp, math=math)
     solver.batch_size = 8
     g = torch.Generator().manual_seed(1234)
     x = torch.rand(8, 3, 64, 64, generator=torch.Generator().manual_seed(0))

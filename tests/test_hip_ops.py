@@ -46,6 +46,42 @@ CONV_CASES = [
 ]
 
 
+@pytest.fixture(params=["fp32", "bf16x6", "bf16x3"])
+def math_mode(request, HF):
+    HF.set_conv_math(request.param)
+    yield request.param
+    HF.set_conv_math("fp32")
+
+
+SPLIT_CASES = [  # shapes the split-bf16 kernel covers (Ci % 32 == 0, Co > 32, KS in {1,3})
+    (2, 32, 8, 8, 40, 3, False), (3, 64, 16, 16, 64, 3, False), (2, 96, 12, 20, 130, 3, False),
+    (4, 128, 4, 4, 256, 3, False), (5, 64, 1, 1, 70, 1, False), (2, 64, 16, 16, 48, 3, True), (2, 512, 4, 4, 64, 3, False),
+]
+
+
+@pytest.mark.parametrize("case", SPLIT_CASES)
+def test_conv_split_bf16_modes(HF, math_mode, case):
+    """Forward and data-gradient in every conv arithmetic against fp64: exact fp32 MFMA and the
+    fp32-class bf16x6 split at 2e-5 of the output scale, bf16x3 at 5e-5 (2^-16 per product)."""
+    B, Ci, H, W, Co, KS, up2 = case
+    assert HF.lib.itcv_conv2d_bf16s_supported(Ci, Co, KS)
+    g = torch.Generator().manual_seed(sum(case[:6]))
+    hs, ws = (H // 2, W // 2) if up2 else (H, W)
+    x = torch.randn(B, Ci, hs, ws, generator=g)
+    w = torch.randn(Co, Ci, KS, KS, generator=g) / (Ci * KS * KS) ** 0.5
+    dy = torch.randn(B, Co, H, W, generator=g)
+    xr, wr = x.double().requires_grad_(True), w.double().requires_grad_(True)
+    xin = F.interpolate(xr, scale_factor=2, mode="nearest") if up2 else xr
+    yr = F.conv2d(xin, wr, padding=KS // 2)
+    yr.backward(dy.double())
+    xd, wd = x.to(dev()).requires_grad_(True), w.to(dev()).requires_grad_(True)
+    y = HF.Conv2dFn.apply(xd, wd, None, up2)
+    y.backward(dy.to(dev()))
+    tol = 5e-5 if math_mode == "bf16x3" else 2e-5
+    assert rel_err(y, yr) < tol and rel_err(xd.grad, xr.grad) < tol
+    assert rel_err(wd.grad, wr.grad) < 2e-5          # the weight gradient stays on the fp32 kernel
+
+
 @pytest.mark.parametrize("case", CONV_CASES)
 def test_conv_forward_backward(HF, case):
     B, Ci, H, W, Co, KS, up2 = case
