@@ -63,6 +63,11 @@ int itcv_conv2d_pack_weight_bf16s(const float* w, void* wp, int Co, int Ci, int 
 size_t itcv_conv2d_fwd_bf16s_workspace(int B, int Ci, int H, int W, int Co, int KS);
 int itcv_conv2d_fwd_bf16s(const float* x, const void* wp, const float* bias, float* y, int B, int Ci, int H,
                           int W, int Co, int KS, int up2, int ns, void* ws, size_t ws_bytes, void* stream);
+/* Split-bf16 weight gradient (same arithmetic, same workspace size as itcv_conv2d_wgrad_workspace):
+ * needs KS in {1,3}, Ci % 32 == 0, W % 8 == 0, Co > 32 and a materialised (not virtually upsampled) x. */
+int itcv_conv2d_wgrad_bf16s_supported(int Ci, int H, int W, int Co, int KS);
+int itcv_conv2d_wgrad_bf16s(const float* x, const float* dy, float* dw, int B, int Ci, int H, int W, int Co,
+                            int KS, int ns, int accumulate, void* ws, size_t ws_bytes, void* stream);
 /* dw[Co][Ci][KS][KS] (+)= sum_{b,h,w} dy[b][co][h][w] * x[b][ci][h+kh-p][w+kw-p]; `up2` as in _fwd
  * (x is the low-resolution [B][Ci][H/2][W/2] tensor, H/W are the dims of dy). */
 size_t itcv_conv2d_wgrad_workspace(int B, int Ci, int H, int W, int Co, int KS);

@@ -392,7 +392,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_fwd_bf16s_kernel(ConvArgsB a
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
           f32x16 c = acc[i][j];
-          if (NS == 3) {   // smallest terms first
+          if constexpr (NS == 3) {   // smallest terms first
             c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][i], bfr[1][j], c, 0, 0, 0);
             c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bfr[2][j], c, 0, 0, 0);
             c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2][i], bfr[0][j], c, 0, 0, 0);
@@ -607,6 +607,185 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_wgrad_kernel(WgradArgs a) {
   }
 }
 
+// ------------------------------------------------------------------------------ split-bf16 wgrad
+// Weight gradient on the bf16 matrix cores (see conv_fwd_bf16s_kernel for the split arithmetic).
+// Both operands are K-contiguous in memory (k = pixel index), which is exactly the MFMA fragment
+// shape: 8 consecutive pixels of one dY row / one shifted X row are one 16-byte chunk per plane.
+// dY chunks are aligned 2 x dwordx4 loads; X chunks are 8 dword loads at the tap-shifted address
+// (per-dword hardware range check; the one pixel that wraps across an image-row edge is masked).
+// Needs W % 8 == 0, KS in {1,3}, Ci % 32 == 0; other shapes stay on the fp32 kernel.
+__device__ __forceinline__ f32x4 buf_load_x4(__amdgpu_buffer_rsrc_t r, uint32_t voff) {
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, 0, 0));
+}
+
+template <int KS, int BM, int CB, int WM, int WN, int NS>
+__global__ __launch_bounds__(WM* WN * 64) void conv_wgrad_bf16s_kernel(WgradArgs a) {
+  constexpr int NT = WM * WN * 64, BK = 32, KC = BK / 8, BN = 128, KK = KS * KS, P = KS / 2, TPB = BN / CB;
+  constexpr int WTM = BM / WM, WTN = BN / WN, TM = WTM / 32, TN = WTN / 32;
+  constexpr int AL = BM / 64, BL = BN / 64;   // 16-row blocks per thread: 4 waves x 16 rows per pass
+  static_assert(NT == 256 && CB >= 32, "loader mapping");
+  __shared__ u32x4 As[NS * KC * BM];
+  __shared__ u32x4 Bs[NS * KC * BN];
+
+  const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
+  const int wm = wid / WN, wn = wid % WN, l31 = lane & 31, half = lane >> 5;
+  const int bid = blockIdx.x, xcd = bid & 7, q = bid >> 3;
+  const int tile = q % a.tiles, sk = (q / a.tiles) * 8 + xcd;
+  if (sk >= a.splits) return;
+  const int tile_m = tile % a.mt, tile_n = tile / a.mt;
+  const int m0 = tile_m * BM;
+  int tap0, ci0;
+  if (CB == 128) {
+    const int per_tap = a.Cip / 128;
+    tap0 = tile_n / per_tap;
+    ci0 = (tile_n - tap0 * per_tap) * 128;
+  } else {
+    tap0 = tile_n * TPB;
+    ci0 = 0;
+  }
+  const int kt0 = sk * a.ktiles_per_split;
+  const int kt1 = min(a.ktiles, kt0 + a.ktiles_per_split);
+  const int H = a.H, W = a.W, HW = H * W;
+  const int sub = lane & 15, kc_l = lane >> 4;          // this lane's row/column within a 16-block, its k chunk
+  const __amdgpu_buffer_rsrc_t rx = make_rsrc(a.x, a.x_bytes);
+  const __amdgpu_buffer_rsrc_t rdy = make_rsrc(a.dy, a.dy_bytes);
+
+  float areg[AL][8], breg[BL][8];
+  auto load_tile = [&](int kt) {
+    const int k = kt * BK + kc_l * 8;                   // first pixel of this lane's chunk
+    const bool kvalid = k < a.Ktot;
+    int bi, hw, h, w0;
+    if (a.hw_shift >= 0) {
+      bi = k >> a.hw_shift;
+      hw = k & (HW - 1);
+    } else {
+      bi = k / HW;
+      hw = k - bi * HW;
+    }
+    if (a.w_shift >= 0) {
+      h = hw >> a.w_shift;
+      w0 = hw & (W - 1);
+    } else {
+      h = hw / W;
+      w0 = hw - h * W;
+    }
+#pragma unroll
+    for (int i = 0; i < AL; ++i) {
+      const int m = m0 + (wid + 4 * i) * 16 + sub;      // rows past Co only feed unstored accumulator rows
+      const uint32_t va = kvalid ? (uint32_t)((bi * a.Co + m) * HW + hw) * 4u : kOobBase;
+      const f32x4 lo = buf_load_x4(rdy, va), hi = buf_load_x4(rdy, va + 16u);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) areg[i][j] = lo[j], areg[i][4 + j] = hi[j];
+    }
+#pragma unroll
+    for (int i = 0; i < BL; ++i) {
+      const int nb = (wid + 4 * i) * 16;                // column block (wave-uniform): one tap, 16 channels
+      const int tl = nb / CB, tap = tap0 + tl;
+      const int ci = ci0 + (nb - tl * CB) + sub;
+      const int dh = tap / KS - P, dw = tap - (tap / KS) * KS - P;
+      const int hh = h + dh;
+      const bool valid = kvalid && tap < KK && ci < a.Ci && (unsigned)hh < (unsigned)H;
+      const uint32_t vb = valid ? (uint32_t)(((bi * a.Ci + ci) * H + hh) * W + w0 + dw) * 4u : kOobBase;
+      // The pixel that would wrap across the image-row edge is padding.  Its load is redirected to the
+      // neighbouring in-range element: hipcc merges consecutive dword loads into dwordx4, and a merged
+      // load that STARTS at offset -4 (first row of the tensor, dw = -1) or ends one past the tensor
+      // (last row, dw = +1) is range-checked as a whole -- the valid pixels beside it came back 0.
+      const bool edge_l = dw < 0 && w0 == 0, edge_r = dw > 0 && w0 + 8 == W;
+      const uint32_t v0 = edge_l ? vb + 4u : vb, v7 = edge_r ? vb + 24u : vb + 28u;
+      breg[i][0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, v0, 0, 0));
+#pragma unroll
+      for (int j = 1; j < 7; ++j)
+        breg[i][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, vb + 4u * j, 0, 0));
+      breg[i][7] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, v7, 0, 0));
+      if (edge_l) breg[i][0] = 0.f;
+      if (edge_r) breg[i][7] = 0.f;
+    }
+  };
+  auto store_tile = [&]() {
+#pragma unroll
+    for (int i = 0; i < AL; ++i) {
+      u32x4 pl[NS];
+      split8<NS>(areg[i], pl);
+#pragma unroll
+      for (int p = 0; p < NS; ++p) As[(p * KC + kc_l) * BM + (wid + 4 * i) * 16 + sub] = pl[p];
+    }
+#pragma unroll
+    for (int i = 0; i < BL; ++i) {
+      u32x4 pl[NS];
+      split8<NS>(breg[i], pl);
+#pragma unroll
+      for (int p = 0; p < NS; ++p) Bs[(p * KC + kc_l) * BN + (wid + 4 * i) * 16 + sub] = pl[p];
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  auto mfma_step = [&]() {
+#pragma unroll
+    for (int ks = 0; ks < BK / 16; ++ks) {
+      const int kc = ks * 2 + half;
+      bf16x8 af[NS][TM], bfr[NS][TN];
+#pragma unroll
+      for (int p = 0; p < NS; ++p) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+          af[p][i] = __builtin_bit_cast(bf16x8, As[(p * KC + kc) * BM + wm * WTM + i * 32 + l31]);
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          bfr[p][j] = __builtin_bit_cast(bf16x8, Bs[(p * KC + kc) * BN + wn * WTN + j * 32 + l31]);
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          f32x16 c = acc[i][j];
+          if constexpr (NS == 3) {
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][i], bfr[1][j], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bfr[2][j], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2][i], bfr[0][j], c, 0, 0, 0);
+          }
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bfr[1][j], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][i], bfr[0][j], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bfr[0][j], c, 0, 0, 0);
+          acc[i][j] = c;
+        }
+    }
+  };
+
+  if (kt0 < kt1) {
+    load_tile(kt0);
+    store_tile();
+    __syncthreads();
+    for (int kt = kt0; kt < kt1; ++kt) {
+      const bool more = kt + 1 < kt1;
+      if (more) load_tile(kt + 1);
+      mfma_step();
+      __syncthreads();
+      if (more) store_tile();
+      __syncthreads();
+    }
+  }
+
+  float* out = a.out + (size_t)sk * a.slab_stride;
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int nl = wn * WTN + j * 32 + l31;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (m < a.Co) out[(size_t)m * a.Np + tile_n * BN + nl] = acc[i][j][r];
+      }
+  }
+}
+
 // dw[co][ci][tap] (+)= sum_s slab[s][co][column(tap, ci)]
 __global__ void splitk_reduce_wgrad(const float* __restrict__ slab, float* __restrict__ dw, int Co, int Ci, int KK,
                                     int Cip, int cb, int Np, size_t slab_stride, int splits, int accumulate) {
@@ -737,29 +916,15 @@ static void launch_fwd(const ConvArgs& a, int bm, int splits, int up2, hipStream
     launch_fwd_cfg<KS, 128, 128, 2, 2>(a, splits, up2, st);
 }
 
-static int wgrad_nbuf() {
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("ITCV_WGRAD_NBUF");
-    v = (e && e[0] == '2') ? 2 : 1;
-  }
-  return v;
-}
-
 template <int KS, int CB, bool UP2>
 static void launch_wgrad_bm(const WgradArgs& a, int bm, hipStream_t st) {
   dim3 grid(cdiv(a.splits, 8) * 8 * a.tiles);
-  const bool two = wgrad_nbuf() == 2;
-  if (bm == 32) {
-    if (two) hipLaunchKernelGGL((conv_wgrad_kernel<KS, 32, CB, 1, 4, UP2, 2>), grid, dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((conv_wgrad_kernel<KS, 32, CB, 1, 4, UP2, 1>), grid, dim3(256), 0, st, a);
-  } else if (bm == 64) {
-    if (two) hipLaunchKernelGGL((conv_wgrad_kernel<KS, 64, CB, 1, 4, UP2, 2>), grid, dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((conv_wgrad_kernel<KS, 64, CB, 1, 4, UP2, 1>), grid, dim3(256), 0, st, a);
-  } else {
-    if (two) hipLaunchKernelGGL((conv_wgrad_kernel<KS, 128, CB, 2, 2, UP2, 2>), grid, dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((conv_wgrad_kernel<KS, 128, CB, 2, 2, UP2, 1>), grid, dim3(256), 0, st, a);
-  }
+  if (bm == 32)
+    hipLaunchKernelGGL((conv_wgrad_kernel<KS, 32, CB, 1, 4, UP2, 1>), grid, dim3(256), 0, st, a);
+  else if (bm == 64)
+    hipLaunchKernelGGL((conv_wgrad_kernel<KS, 64, CB, 1, 4, UP2, 1>), grid, dim3(256), 0, st, a);
+  else
+    hipLaunchKernelGGL((conv_wgrad_kernel<KS, 128, CB, 2, 2, UP2, 1>), grid, dim3(256), 0, st, a);
 }
 template <int KS, bool UP2>
 static void launch_wgrad_cb(const WgradArgs& a, int bm, int cb, hipStream_t st) {
@@ -817,6 +982,24 @@ static void launch_fwd_b(const ConvArgsB& a, int bm, int splits, int up2, hipStr
     if (up2) hipLaunchKernelGGL((conv_fwd_bf16s_kernel<KS, 128, 128, 2, 2, true, NS>), grid, block, 0, st, a);
     else hipLaunchKernelGGL((conv_fwd_bf16s_kernel<KS, 128, 128, 2, 2, false, NS>), grid, block, 0, st, a);
   }
+}
+
+template <int KS, int CB, int NS>
+static void launch_wgrad_b_bm(const WgradArgs& a, int bm, hipStream_t st) {
+  dim3 grid(cdiv(a.splits, 8) * 8 * a.tiles);
+  if (bm == 64)
+    hipLaunchKernelGGL((conv_wgrad_bf16s_kernel<KS, 64, CB, 1, 4, NS>), grid, dim3(256), 0, st, a);
+  else
+    hipLaunchKernelGGL((conv_wgrad_bf16s_kernel<KS, 128, CB, 2, 2, NS>), grid, dim3(256), 0, st, a);
+}
+template <int KS, int NS>
+static void launch_wgrad_b(const WgradArgs& a, int bm, int cb, hipStream_t st) {
+  if (cb == 32)
+    launch_wgrad_b_bm<KS, 32, NS>(a, bm, st);
+  else if (cb == 64)
+    launch_wgrad_b_bm<KS, 64, NS>(a, bm, st);
+  else
+    launch_wgrad_b_bm<KS, 128, NS>(a, bm, st);
 }
 
 static int check_dims(const char* name, int B, int Ci, int H, int W, int Co, int KS) {
@@ -1024,6 +1207,54 @@ int itcv_conv2d_wgrad(const float* x, const float* dy, float* dw, int B, int Ci,
   hipLaunchKernelGGL(splitk_reduce_wgrad, dim3(blocks), dim3(256), 0, st, static_cast<const float*>(ws), dw, Co, Ci,
                      KS * KS, p.cip, p.cb, a.Np, slab, p.splits, accumulate);
   ITCV_CHECK_LAUNCH("itcv_conv2d_wgrad(reduce)");
+  return 0;
+}
+
+// ---- split-bf16 weight gradient ---------------------------------------------------------------
+int itcv_conv2d_wgrad_bf16s_supported(int Ci, int H, int W, int Co, int KS) {
+  return (KS == 1 || KS == 3) && Ci % 32 == 0 && W % 8 == 0 && Co >= 33 && H > 0;
+}
+
+int itcv_conv2d_wgrad_bf16s(const float* x, const float* dy, float* dw, int B, int Ci, int H, int W, int Co, int KS,
+                            int ns, int accumulate, void* ws, size_t ws_bytes, void* stream) {
+  if (int e = check_dims("itcv_conv2d_wgrad_bf16s", B, Ci, H, W, Co, KS)) return e;
+  ITCV_REQUIRE(x && dy && dw && (ns == 2 || ns == 3), "itcv_conv2d_wgrad_bf16s");
+  if (!itcv_conv2d_wgrad_bf16s_supported(Ci, H, W, Co, KS))
+    return fail("%s: shape not supported by the split-bf16 kernel (Ci %% 32, W %% 8, Co > 32, KS 1/3)",
+                "itcv_conv2d_wgrad_bf16s");
+  WgPlan p = plan_wgrad(B, Ci, H, W, Co, KS);     // same tiling / slab layout as the fp32 kernel
+  if (p.bm < 64) p.bm = 64, p.mt = cdiv(Co, 64), p.tiles = p.mt * p.nt;
+  const size_t slab = (size_t)Co * p.nt * 128;
+  if (!ws || ws_bytes < (size_t)p.splits * slab * sizeof(float))
+    return fail("%s: workspace too small (need %lld bytes)", "itcv_conv2d_wgrad_bf16s",
+                (long long)((size_t)p.splits * slab * sizeof(float)));
+  WgradArgs a;
+  a.x = x, a.dy = dy;
+  a.out = static_cast<float*>(ws);
+  a.B = B, a.Ci = Ci, a.H = H, a.W = W, a.Co = Co;
+  a.Cip = p.cip;
+  a.Np = p.nt * 128;
+  a.Ktot = B * H * W;
+  a.mt = p.mt, a.nt = p.nt, a.tiles = p.tiles;
+  a.ktiles = p.ktiles, a.ktiles_per_split = p.kps, a.splits = p.splits;
+  a.w_shift = log2_exact(W), a.hw_shift = log2_exact(H * W);
+  a.x_bytes = (uint32_t)((size_t)B * Ci * H * W * sizeof(float));
+  a.dy_bytes = (uint32_t)((size_t)B * Co * H * W * sizeof(float));
+  a.slab_stride = slab;
+  hipStream_t st = S(stream);
+  if (KS == 1) {
+    if (ns == 2) launch_wgrad_b<1, 2>(a, p.bm, p.cb, st);
+    else launch_wgrad_b<1, 3>(a, p.bm, p.cb, st);
+  } else {
+    if (ns == 2) launch_wgrad_b<3, 2>(a, p.bm, p.cb, st);
+    else launch_wgrad_b<3, 3>(a, p.bm, p.cb, st);
+  }
+  ITCV_CHECK_LAUNCH("itcv_conv2d_wgrad_bf16s");
+  const size_t dw_elems = (size_t)Co * Ci * KS * KS;
+  const int blocks = (int)(cdivz(dw_elems, 256) < 2048 ? cdivz(dw_elems, 256) : 2048);
+  hipLaunchKernelGGL(splitk_reduce_wgrad, dim3(blocks), dim3(256), 0, st, static_cast<const float*>(ws), dw, Co, Ci,
+                     KS * KS, p.cip, p.cb, a.Np, slab, p.splits, accumulate);
+  ITCV_CHECK_LAUNCH("itcv_conv2d_wgrad_bf16s(reduce)");
   return 0;
 }
 

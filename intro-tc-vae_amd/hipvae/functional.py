@@ -206,6 +206,26 @@ def conv_wgrad_raw(x, dy, B, Ci, H, W, Co, KS, up2, out=None, accumulate=False):
     dw = out if out is not None else torch.empty((Co, Ci, KS, KS), dtype=F32, device=x.device)
     nws = lib.itcv_conv2d_wgrad_workspace(B, Ci, H, W, Co, KS)
     ws = _ws(nws, x.device)
+    ns = _NS[_CONV_MATH[0]]
+    if ns and lib.itcv_conv2d_wgrad_bf16s_supported(Ci, H, W, Co, KS):
+        if up2:   # the split kernel reads 8-pixel chunks: materialise the x2 nearest upsampling once
+            xu = torch.empty((B, Ci, H, W), dtype=F32, device=x.device)
+            call("itcv_upsample2_fwd", ptr(x), ptr(xu), B * Ci, H // 2, W // 2, stream())
+            x = xu
+
+        def launch_b():
+            call("itcv_conv2d_wgrad_bf16s", ptr(x), ptr(dy), ptr(dw), B, Ci, H, W, Co, KS, ns, int(accumulate),
+                 ptr(ws), nws, stream())
+            return dw
+        if LaunchProfile.active is None:
+            return launch_b()
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        launch_b()
+        e.record()
+        LaunchProfile.active.append((f"conv_wgrad_bf16s_kernel<KS={KS},BM={64 if Co <= 64 else 128},NS={ns}>+reduce",
+                                     2.0 * B * H * W * Co * Ci * KS * KS, s, e))
+        return dw
 
     def launch():
         call("itcv_conv2d_wgrad", ptr(x), ptr(dy), ptr(dw), B, Ci, H, W, Co, KS, int(up2), int(accumulate), ptr(ws),

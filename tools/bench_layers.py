@@ -51,6 +51,12 @@ def main():
                 t3 = timeit(lambda: HF.conv_apply(x, w, w, 0, None, B, Ci, S, S, Co, KS, False))
                 err = float((HF.conv_apply(x, w, w, 0, None, B, Ci, S, S, Co, KS, False) - ref).abs().max() / ref.abs().max())
                 extra += f" | {mode} {t3*1e3:6.3f} ms {gf/t3*1e-3:6.1f} TFeq err {err:.1e}"
+                if HF.lib.itcv_conv2d_wgrad_bf16s_supported(Ci, S, S, Co, KS):
+                    refw = None
+                    HF.set_conv_math("fp32"); refw = HF.conv_wgrad_raw(x, dy, B, Ci, S, S, Co, KS, False); HF.set_conv_math(mode)
+                    tw3 = timeit(lambda: HF.conv_wgrad_raw(x, dy, B, Ci, S, S, Co, KS, False))
+                    errw = float((HF.conv_wgrad_raw(x, dy, B, Ci, S, S, Co, KS, False) - refw).abs().max() / refw.abs().max())
+                    extra += f" wg {tw3*1e3:6.3f} ms {gf/tw3*1e-3:6.1f} err {errw:.1e}"
             HF.set_conv_math("fp32")
         print(f"{Ci:4d}->{Co:4d}@{S:3d} k{KS} B{B:3d} {gf:7.2f} | {tf*1e3:8.3f} {gf/tf*1e-3:6.1f} | "
               f"{td*1e3:8.3f} {gf/td*1e-3:6.1f} | {tw*1e3:8.3f} {gf/tw*1e-3:6.1f}" + extra)
