@@ -63,6 +63,13 @@ int itcv_conv2d_pack_weight_bf16s(const float* w, void* wp, int Co, int Ci, int 
 size_t itcv_conv2d_fwd_bf16s_workspace(int B, int Ci, int H, int W, int Co, int KS);
 int itcv_conv2d_fwd_bf16s(const float* x, const void* wp, const float* bias, float* y, int B, int Ci, int H,
                           int W, int Co, int KS, int up2, int ns, void* ws, size_t ws_bytes, void* stream);
+/* Direct (vector-ALU, exact fp32) convolution for layers with at most 4 output channels -- the 5x5
+ * predict conv 64->3 (models.py:290) and the data-gradient of the 5x5 stem (models.py:213), where a
+ * 32-row MFMA tile would be >90 % padding.  for_dgrad = 0: w is [Co][C][KS][KS]; for_dgrad = 1: w is the
+ * forward layer's [C][Co][KS][KS] and its transposed, flipped filter is applied to x = dy. */
+int itcv_conv2d_small_cout_supported(int Co, int KS);
+int itcv_conv2d_small_cout_fwd(const float* x, const float* w, const float* bias, float* y, int B, int C,
+                               int H, int W, int Co, int KS, int for_dgrad, void* stream);
 /* Split-bf16 weight gradient (same arithmetic, same workspace size as itcv_conv2d_wgrad_workspace):
  * needs KS in {1,3}, Ci % 32 == 0, W % 8 == 0, Co > 32 and a materialised (not virtually upsampled) x. */
 int itcv_conv2d_wgrad_bf16s_supported(int Ci, int H, int W, int Co, int KS);

@@ -1,0 +1,120 @@
+// Direct convolution for layers with at most 4 OUTPUT channels (the 5x5 "predict" conv 64->3 of the
+// decoder, models.py:290, and the data-gradient of the 5x5 stem 3<-64, models.py:213).
+//
+// With M = 3 a 32-row MFMA tile is 91 % padding (the implicit-GEMM kernel ran these layers at
+// ~10 TFLOP/s); they are done on the vector ALUs instead: one workgroup owns a 16x16 output tile of
+// one image, stages the (16+KS-1)^2 input patch of 8 channels at a time in LDS (zero-filled halo),
+// and every thread accumulates its pixel's CO outputs with the weights as wave-uniform scalar
+// operands (s_load) -- 3 FMAs per LDS read.  fp32 throughout (exact, like the fp32 MFMA path).
+#include "common.h"
+
+namespace itcv {
+
+constexpr int kTile = 16, kChunk = 8;
+
+// weight of (output channel m, reduction channel c, tap): forward reads w[m][c][tap] of the OIHW
+// tensor, the data-gradient reads the transposed, flipped filter w[c][m][KK-1-tap].
+template <int KS, int CO, bool DGRAD>
+__global__ __launch_bounds__(256) void conv_small_cout_kernel(const float* __restrict__ x,
+                                                             const float* __restrict__ w,
+                                                             const float* __restrict__ bias, float* __restrict__ y,
+                                                             int C, int H, int W, int Cw, int tiles_x, int tiles_y) {
+  constexpr int KK = KS * KS, P = KS / 2, PW = kTile + KS - 1, PSZ = PW * PW;
+  __shared__ float patch[kChunk * PSZ];
+  const int t = threadIdx.x, tx = t & 15, ty = t >> 4;
+  int bid = blockIdx.x;
+  const int tile_x = bid % tiles_x;
+  bid /= tiles_x;
+  const int tile_y = bid % tiles_y, b = bid / tiles_y;
+  const int h0 = tile_y * kTile, w0 = tile_x * kTile;
+  const float* xb = x + (size_t)b * C * H * W;
+
+  float acc[CO];
+#pragma unroll
+  for (int m = 0; m < CO; ++m) acc[m] = 0.f;
+
+  for (int c0 = 0; c0 < C; c0 += kChunk) {
+    __syncthreads();
+    for (int i = t; i < kChunk * PSZ; i += 256) {
+      const int c = i / PSZ, r = i - c * PSZ, ph = r / PW, pw = r - ph * PW;
+      const int hh = h0 + ph - P, ww = w0 + pw - P;
+      float v = 0.f;
+      if (c0 + c < C && (unsigned)hh < (unsigned)H && (unsigned)ww < (unsigned)W)
+        v = xb[((size_t)(c0 + c) * H + hh) * W + ww];
+      patch[i] = v;
+    }
+    __syncthreads();
+    const int nc = min(kChunk, C - c0);
+    for (int c = 0; c < nc; ++c) {
+      const float* pc = patch + c * PSZ + ty * PW + tx;
+      // wave-uniform weight row(s) for this reduction channel
+      const float* wc[CO];
+#pragma unroll
+      for (int m = 0; m < CO; ++m)
+        wc[m] = DGRAD ? w + ((size_t)(c0 + c) * Cw + m) * KK : w + ((size_t)m * Cw + (c0 + c)) * KK;
+#pragma unroll
+      for (int kh = 0; kh < KS; ++kh)
+#pragma unroll
+        for (int kw = 0; kw < KS; ++kw) {
+          const float xv = pc[kh * PW + kw];
+          const int tap = DGRAD ? KK - 1 - (kh * KS + kw) : kh * KS + kw;
+#pragma unroll
+          for (int m = 0; m < CO; ++m) acc[m] = fmaf(wc[m][tap], xv, acc[m]);
+        }
+    }
+  }
+  const int h = h0 + ty, ww = w0 + tx;
+  if (h < H && ww < W) {
+#pragma unroll
+    for (int m = 0; m < CO; ++m)
+      y[(((size_t)b * CO + m) * H + h) * W + ww] = acc[m] + (bias ? bias[m] : 0.f);
+  }
+}
+
+}  // namespace itcv
+
+using namespace itcv;
+
+extern "C" {
+
+int itcv_conv2d_small_cout_supported(int Co, int KS) { return Co >= 1 && Co <= 4 && (KS == 3 || KS == 5); }
+
+// y[B][Co][H][W] = conv(x[B][C][H][W], w) (+bias), Co <= 4.  for_dgrad = 0: w is [Co][C][KS][KS];
+// for_dgrad = 1: w is the forward layer's [C][Co][KS][KS] and the transposed, flipped filter is applied
+// (x is then the output gradient, y the input gradient).
+int itcv_conv2d_small_cout_fwd(const float* x, const float* w, const float* bias, float* y, int B, int C, int H,
+                               int W, int Co, int KS, int for_dgrad, void* stream) {
+  ITCV_REQUIRE(x && w && y && B > 0 && C > 0 && H > 0 && W > 0, "itcv_conv2d_small_cout_fwd");
+  if (!itcv_conv2d_small_cout_supported(Co, KS))
+    return fail("%s: needs 1 <= Co <= 4 and KS in {3,5}", "itcv_conv2d_small_cout_fwd");
+  const int tx = cdiv(W, kTile), ty = cdiv(H, kTile);
+  dim3 grid(B * tx * ty), block(256);
+  hipStream_t st = S(stream);
+  const int Cw = for_dgrad ? Co : C;   // inner dimension of the weight tensor as indexed by the kernel
+#define ITCV_SMALL(KS_, CO_)                                                                                       \
+  do {                                                                                                             \
+    if (for_dgrad)                                                                                                 \
+      hipLaunchKernelGGL((conv_small_cout_kernel<KS_, CO_, true>), grid, block, 0, st, x, w, bias, y, C, H, W, Cw, \
+                         tx, ty);                                                                                  \
+    else                                                                                                           \
+      hipLaunchKernelGGL((conv_small_cout_kernel<KS_, CO_, false>), grid, block, 0, st, x, w, bias, y, C, H, W,    \
+                         Cw, tx, ty);                                                                              \
+  } while (0)
+#define ITCV_SMALL_KS(KS_)                    \
+  do {                                        \
+    if (Co == 1) ITCV_SMALL(KS_, 1);          \
+    else if (Co == 2) ITCV_SMALL(KS_, 2);     \
+    else if (Co == 3) ITCV_SMALL(KS_, 3);     \
+    else ITCV_SMALL(KS_, 4);                  \
+  } while (0)
+  if (KS == 3)
+    ITCV_SMALL_KS(3);
+  else
+    ITCV_SMALL_KS(5);
+#undef ITCV_SMALL_KS
+#undef ITCV_SMALL
+  ITCV_CHECK_LAUNCH("itcv_conv2d_small_cout_fwd");
+  return 0;
+}
+
+}  // extern "C"

@@ -127,6 +127,16 @@ def pack_weight_bf16s(w4, for_dgrad, ns):
 def conv_apply(x, weight, w4, for_dgrad, bias, B, Ci, H, W, Co, KS, up2):
     """Forward-type conv GEMM (forward, or data-gradient with the roles of Ci/Co swapped by the caller)
     on the kernel selected by set_conv_math()."""
+    if not up2 and lib.itcv_conv2d_small_cout_supported(Co, KS):
+        # <= 4 output channels: direct fp32 conv on the vector ALUs, reads the raw OIHW weights
+        y = torch.empty((B, Co, H, W), dtype=F32, device=x.device)
+
+        def launch_small():
+            call("itcv_conv2d_small_cout_fwd", ptr(x), ptr(w4), ptr(bias), ptr(y), B, Ci, H, W, Co, KS, int(for_dgrad),
+                 stream())
+            return y
+        return _profiled_label(f"conv_small_cout_kernel<KS={KS},CO={Co}>", 2.0 * B * H * W * Co * Ci * KS * KS,
+                               launch_small)
     ns = _NS[_CONV_MATH[0]]
     if ns and lib.itcv_conv2d_bf16s_supported(Ci, Co, KS):
         wp = packed_weight(weight, w4, for_dgrad, ns)
@@ -175,6 +185,17 @@ class LaunchProfile:
 
 def _label(kind, v):
     return f"conv_{kind}_kernel<KS={(v >> 8) & 255},BM={v & 255},up2={(v >> 16) & 1}>/splitK={v >> 20}"
+
+
+def _profiled_label(label, flop, launch):
+    if LaunchProfile.active is None:
+        return launch()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    out = launch()
+    e.record()
+    LaunchProfile.active.append((label, flop, s, e))
+    return out
 
 
 def _profiled(kind, variant, flop, launch):
