@@ -70,6 +70,11 @@ int itcv_conv2d_fwd_bf16s(const float* x, const void* wp, const float* bias, flo
 int itcv_conv2d_small_cout_supported(int Co, int KS);
 int itcv_conv2d_small_cout_fwd(const float* x, const float* w, const float* bias, float* y, int B, int C,
                                int H, int W, int Co, int KS, int for_dgrad, void* stream);
+/* ... and for layers with at most 4 REDUCTION channels (the 5x5 stem 3->64 forward, models.py:213, and
+ * the data-gradient of the predict conv): the pixel's input window lives in registers. */
+int itcv_conv2d_small_cin_supported(int C, int KS);
+int itcv_conv2d_small_cin_fwd(const float* x, const float* w, const float* bias, float* y, int B, int C, int H,
+                              int W, int Co, int KS, int for_dgrad, void* stream);
 /* Split-bf16 weight gradient (same arithmetic, same workspace size as itcv_conv2d_wgrad_workspace):
  * needs KS in {1,3}, Ci % 32 == 0, W % 8 == 0, Co > 32 and a materialised (not virtually upsampled) x. */
 int itcv_conv2d_wgrad_bf16s_supported(int Ci, int H, int W, int Co, int KS);

@@ -71,6 +71,53 @@ __global__ __launch_bounds__(256) void conv_small_cout_kernel(const float* __res
   }
 }
 
+// ---- at most 4 REDUCTION channels (the 5x5 stem 3->64 forward, and the data-gradient of the predict
+// conv 3->64): every thread keeps its pixel's CI*KS*KS input window in registers and walks the output
+// channels with wave-uniform scalar weights -- one FMA per weight, no LDS traffic in the inner loop.
+template <int KS, int CI, bool DGRAD>
+__global__ __launch_bounds__(256) void conv_small_cin_kernel(const float* __restrict__ x,
+                                                            const float* __restrict__ w,
+                                                            const float* __restrict__ bias, float* __restrict__ y,
+                                                            int M, int H, int W, int tiles_x, int tiles_y) {
+  constexpr int KK = KS * KS, P = KS / 2, PW = kTile + KS - 1, PSZ = PW * PW;
+  __shared__ float patch[CI * PSZ];
+  const int t = threadIdx.x, tx = t & 15, ty = t >> 4;
+  int bid = blockIdx.x;
+  const int tile_x = bid % tiles_x;
+  bid /= tiles_x;
+  const int tile_y = bid % tiles_y, b = bid / tiles_y;
+  const int h0 = tile_y * kTile, w0 = tile_x * kTile;
+  const float* xb = x + (size_t)b * CI * H * W;
+  for (int i = t; i < CI * PSZ; i += 256) {
+    const int c = i / PSZ, r = i - c * PSZ, ph = r / PW, pw = r - ph * PW;
+    const int hh = h0 + ph - P, ww = w0 + pw - P;
+    patch[i] = ((unsigned)hh < (unsigned)H && (unsigned)ww < (unsigned)W) ? xb[((size_t)c * H + hh) * W + ww] : 0.f;
+  }
+  __syncthreads();
+  float xv[CI * KK];
+#pragma unroll
+  for (int c = 0; c < CI; ++c)
+#pragma unroll
+    for (int kh = 0; kh < KS; ++kh)
+#pragma unroll
+      for (int kw = 0; kw < KS; ++kw) xv[c * KK + kh * KS + kw] = patch[c * PSZ + (ty + kh) * PW + tx + kw];
+  const int h = h0 + ty, ww = w0 + tx;
+  const bool inside = h < H && ww < W;
+  float* yb = y + ((size_t)b * M * H + h) * W + ww;
+  for (int m = 0; m < M; ++m) {
+    float acc = bias ? bias[m] : 0.f;
+#pragma unroll
+    for (int c = 0; c < CI; ++c)
+#pragma unroll
+      for (int tap = 0; tap < KK; ++tap) {
+        // forward: w[m][c][tap] of [M][CI][KK]; data-gradient: w[c][m][KK-1-tap] of [CI][M][KK]
+        const float wv = DGRAD ? w[((size_t)c * M + m) * KK + (KK - 1 - tap)] : w[((size_t)m * CI + c) * KK + tap];
+        acc = fmaf(wv, xv[c * KK + tap], acc);
+      }
+    if (inside) yb[(size_t)m * H * W] = acc;
+  }
+}
+
 }  // namespace itcv
 
 using namespace itcv;
@@ -114,6 +161,44 @@ int itcv_conv2d_small_cout_fwd(const float* x, const float* w, const float* bias
 #undef ITCV_SMALL_KS
 #undef ITCV_SMALL
   ITCV_CHECK_LAUNCH("itcv_conv2d_small_cout_fwd");
+  return 0;
+}
+
+int itcv_conv2d_small_cin_supported(int C, int KS) { return C >= 1 && C <= 4 && (KS == 3 || KS == 5); }
+
+// y[B][Co][H][W] = conv(x[B][C][H][W], w) (+bias), C <= 4 reduction channels.  for_dgrad = 0: w is
+// [Co][C][KS][KS]; for_dgrad = 1: w is the forward layer's [C][Co][KS][KS] (x = dy of that layer).
+int itcv_conv2d_small_cin_fwd(const float* x, const float* w, const float* bias, float* y, int B, int C, int H,
+                              int W, int Co, int KS, int for_dgrad, void* stream) {
+  ITCV_REQUIRE(x && w && y && B > 0 && Co > 0 && H > 0 && W > 0, "itcv_conv2d_small_cin_fwd");
+  if (!itcv_conv2d_small_cin_supported(C, KS))
+    return fail("%s: needs 1 <= C <= 4 and KS in {3,5}", "itcv_conv2d_small_cin_fwd");
+  const int tx = cdiv(W, kTile), ty = cdiv(H, kTile);
+  dim3 grid(B * tx * ty), block(256);
+  hipStream_t st = S(stream);
+#define ITCV_SCIN(KS_, CI_)                                                                                      \
+  do {                                                                                                           \
+    if (for_dgrad)                                                                                               \
+      hipLaunchKernelGGL((conv_small_cin_kernel<KS_, CI_, true>), grid, block, 0, st, x, w, bias, y, Co, H, W, tx, \
+                         ty);                                                                                    \
+    else                                                                                                         \
+      hipLaunchKernelGGL((conv_small_cin_kernel<KS_, CI_, false>), grid, block, 0, st, x, w, bias, y, Co, H, W,  \
+                         tx, ty);                                                                                \
+  } while (0)
+#define ITCV_SCIN_KS(KS_)                 \
+  do {                                    \
+    if (C == 1) ITCV_SCIN(KS_, 1);        \
+    else if (C == 2) ITCV_SCIN(KS_, 2);   \
+    else if (C == 3) ITCV_SCIN(KS_, 3);   \
+    else ITCV_SCIN(KS_, 4);               \
+  } while (0)
+  if (KS == 3)
+    ITCV_SCIN_KS(3);
+  else
+    ITCV_SCIN_KS(5);
+#undef ITCV_SCIN_KS
+#undef ITCV_SCIN
+  ITCV_CHECK_LAUNCH("itcv_conv2d_small_cin_fwd");
   return 0;
 }
 

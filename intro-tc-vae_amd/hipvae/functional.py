@@ -137,6 +137,15 @@ def conv_apply(x, weight, w4, for_dgrad, bias, B, Ci, H, W, Co, KS, up2):
             return y
         return _profiled_label(f"conv_small_cout_kernel<KS={KS},CO={Co}>", 2.0 * B * H * W * Co * Ci * KS * KS,
                                launch_small)
+    if not up2 and lib.itcv_conv2d_small_cin_supported(Ci, KS):
+        # <= 4 reduction channels: direct fp32 conv, the pixel's input window lives in registers
+        y = torch.empty((B, Co, H, W), dtype=F32, device=x.device)
+
+        def launch_scin():
+            call("itcv_conv2d_small_cin_fwd", ptr(x), ptr(w4), ptr(bias), ptr(y), B, Ci, H, W, Co, KS, int(for_dgrad),
+                 stream())
+            return y
+        return _profiled_label(f"conv_small_cin_kernel<KS={KS},CI={Ci}>", 2.0 * B * H * W * Co * Ci * KS * KS, launch_scin)
     ns = _NS[_CONV_MATH[0]]
     if ns and lib.itcv_conv2d_bf16s_supported(Ci, Co, KS):
         wp = packed_weight(weight, w4, for_dgrad, ns)
