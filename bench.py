@@ -8,8 +8,8 @@ z_dim=128, batch 64 per GPU, conv architecture -- BASELINE.json configs[1] (c2),
            --master-port P bench.py --gpus N --steps K --warmup W
 
 One process per GPU; N>1 shards the batch (weak scaling, 64 images per GPU) with a flat RCCL
-all-reduce of the trained half's gradients per phase, an all-gather of mu for the full-batch TC
-estimator and Sync-BN moments.  Rank 0 prints ONE JSON line.  Inputs are resident in HBM before
+all-reduce of the trained half's gradients per phase and an all-gather of mu for the full-batch TC
+estimator; BatchNorm statistics are per rank (throughput mode) unless --sync-bn (parity mode).  Rank 0 prints ONE JSON line.  Inputs are resident in HBM before
 the timed region; the timed region is bracketed by barrier + synchronize on both sides and the
 maximum over ranks is reported.
 
@@ -106,7 +106,8 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-sync-bn", action="store_true", help="per-rank BatchNorm statistics (throughput mode)")
+    ap.add_argument("--sync-bn", action="store_true",
+                    help="N>1: all-reduce BatchNorm moments (full-batch parity mode); default is per-rank statistics")
     ap.add_argument("--math", choices=["bf16x3", "bf16x6", "fp32"], default="bf16x3",
                     help="conv GEMM arithmetic: bf16x3 = use_amp=True (the reference's config default), split-bf16 "
                          "MFMA with fp32 accumulate; bf16x6 = fp32-class 3-way split; fp32 = exact fp32 MFMA")
@@ -132,7 +133,7 @@ def main():
     from solvers.intro_tc import IntroTCSovler
 
     if world > 1:
-        ddp.init(sync_bn=not args.no_sync_bn)
+        ddp.init(sync_bn=args.sync_bn)
     torch.manual_seed(0)
     with contextlib.redirect_stdout(io.StringIO()):
         model = models.SoftIntroVAE(arch="conv", **CFG)
@@ -189,11 +190,11 @@ def main():
 
     # ---- roofline of the dominant kernel from the live HIP-event records -------------------
     buckets = {}
-    for label, flop, s, e in records:
+    for label, flop, secs in records:
         b = buckets.setdefault(label, [0, 0.0, 0.0])
         b[0] += 1
         b[1] += flop
-        b[2] += s.elapsed_time(e) * 1e-3
+        b[2] += secs
     conv_time = sum(b[2] for b in buckets.values())
     conv_flop = sum(b[1] for b in buckets.values())
     dom_label, dom = max(buckets.items(), key=lambda kv: kv[1][2])
@@ -203,14 +204,30 @@ def main():
         peak, peak_note = PEAK_BF16_MFMA_TFLOPS / products, f"2500 TFLOP/s dense bf16 MFMA / {products} bf16 products per fp32 product"
     else:
         peak, peak_note = PEAK_F32_MFMA_TFLOPS, "dense fp32 MFMA"
+    traffic, traffic_note = None, None
+    try:   # HBM bytes per launch from the committed rocprofv3 --pmc passes over this same command
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+        fam = dom_label.split("<")[0]
+        args_ = dom_label[dom_label.index("<") + 1:-1].split(",")
+        want = [a.split("=")[1] for a in args_]
+        for name, rec in pmc["kernels"].items():
+            if fam + "<" in name and args.math == "bf16x3":
+                targs = name[name.index("<") + 1:name.index(">")].replace(" ", "").split(",")
+                # template order: KS, BM, BN, WM, WN, UP2, NS  vs label KS, BM, up2, NS
+                if targs[0] == want[0] and targs[1] == want[1] and targs[-1] == want[-1] and targs[-2] == ("true" if want[2] == "1" else "false"):
+                    traffic = rec["hbm_bytes_per_launch_fetch_x2"]
+                    traffic_note = ("profiles/r01_pmc_traffic.json: (2*FETCH_SIZE + WRITE_SIZE)*1024 per launch, rocprofv3 --pmc, "
+                                    f"separate passes; raw (uncorrected) = {rec['hbm_bytes_per_launch_raw']}")
+    except Exception:  # noqa: BLE001
+        pass
     roofline = {
         "bound": "mfma", "kernel": dom_label, "achieved": round(achieved, 2), "peak": round(peak, 1),
-        "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": None, "peak_note": peak_note,
+        "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_note": traffic_note, "peak_note": peak_note,
         "launches_per_step": dom[0] / args.steps, "avg_launch_us": round(dom[2] / dom[0] * 1e6, 2),
         "algorithmic_gflop_per_launch": round(dom[1] / dom[0] * 1e-9, 3),
         "all_conv_kernels": {"achieved": round(conv_flop / conv_time * 1e-12, 2),
                              "share_of_eager_step_time": round(conv_time / eager_elapsed, 3)},
-        "measured": f"HIP events around every launch during {args.steps} eager steps of this workload, same process"
+        "measured": f"HIP event pairs recorded inside libitcv_hip.so on the launch stream around every main conv kernel during {args.steps} eager steps of this workload, same process"
                     + (", immediately before the timed hipGraph-replay steps" if use_graph else " (the timed region)"),
     }
 
@@ -226,7 +243,7 @@ def main():
         "config": {"workload": "c2: IntroTCSovler.train_step, conv arch, 64x64x3, z_dim=128, channels (64,128,256,512), "
                                f"batch {B_PER_GPU}/GPU, Adam lr 2e-4, clip 100, N=10000",
                    "global_batch": B_PER_GPU * world, "parallelism": f"dp{world}" if world > 1 else "single",
-                   "sync_bn": bool(world > 1 and not args.no_sync_bn)},
+                   "sync_bn": bool(world > 1 and args.sync_bn)},
         "execution": "hipGraph replay (whole step = one graph)" if use_graph else "eager launches",
         "eager_ms_per_step": round(eager_elapsed / args.steps * 1e3, 3),
         "step_tflop": round(STEP_GFLOP_PER_IMAGE * B_PER_GPU * world * 1e-3, 3),

@@ -31,6 +31,16 @@ extern "C" {
 int itcv_abi_version(void);
 const char* itcv_last_error(void);
 
+/* Optional per-launch timing of the GEMM-class kernels (bench.py's roofline leg): between _begin and
+ * _end every conv entry point records a HIP event pair on its launch stream around its MAIN kernel
+ * (not the split-K reduce).  _end waits for the events and returns the record count; record i is
+ * (code = kind | KS<<4 | BM<<8 | up2<<16 | NS<<20 with kind 0 fwd fp32, 1 fwd split-bf16, 2 wgrad fp32,
+ * 3 wgrad split-bf16, 4 small-Cout direct, 5 small-Cin direct; algorithmic FLOP; elapsed ms). */
+int itcv_profile_begin(void);
+int itcv_profile_end(void);
+int itcv_profile_get(int i, int* code, double* flop, float* ms);
+int itcv_profile_clear(void);
+
 /* ---- convolution / linear: implicit GEMM on v_mfma_f32_32x32x2_f32 -------------------
  * Stride 1, square odd kernel KS in {1,3,5}, zero padding KS/2 ("same"), groups 1.
  * Replaces nn.Conv2d / nn.Linear forward+backward: models.py:28-47 (3x3 blocks), :213

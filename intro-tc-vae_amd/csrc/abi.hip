@@ -1,11 +1,65 @@
 // Library-level entry points of libitcv_hip.so (error reporting, ABI version).
 #include "common.h"
 
+#include <vector>
+
 namespace itcv {
 thread_local char g_err[512] = "";
+
+struct ProfRec {
+  int code;
+  double flop;
+  hipEvent_t start, stop;
+};
+static bool g_prof_on = false;
+static std::vector<ProfRec> g_prof;
+
+ProfScope::ProfScope(hipStream_t stream, int kind, int ks, int bm, int up2, int ns, double flop) : st(stream), slot(-1) {
+  if (!g_prof_on) return;
+  ProfRec r;
+  r.code = kind | (ks << 4) | (bm << 8) | (up2 << 16) | (ns << 20);
+  r.flop = flop;
+  if (hipEventCreate(&r.start) != hipSuccess || hipEventCreate(&r.stop) != hipSuccess) return;
+  (void)hipEventRecord(r.start, st);
+  g_prof.push_back(r);
+  slot = (int)g_prof.size() - 1;
+}
+ProfScope::~ProfScope() {
+  if (slot >= 0) (void)hipEventRecord(g_prof[slot].stop, st);
+}
 }
 
 extern "C" {
 int itcv_abi_version(void) { return ITCV_ABI_VERSION; }
 const char* itcv_last_error(void) { return itcv::g_err; }
+
+int itcv_profile_begin(void) {
+  itcv::g_prof.clear();
+  itcv::g_prof_on = true;
+  return 0;
+}
+// stops recording, waits for the recorded events and returns the number of records
+int itcv_profile_end(void) {
+  itcv::g_prof_on = false;
+  for (auto& r : itcv::g_prof) (void)hipEventSynchronize(r.stop);
+  return (int)itcv::g_prof.size();
+}
+// record i: code = kind | KS<<4 | BM<<8 | up2<<16 | NS<<20 (kind 0 fwd fp32, 1 fwd split-bf16, 2 wgrad fp32,
+// 3 wgrad split-bf16, 4 small-Cout direct, 5 small-Cin direct), algorithmic FLOP, elapsed milliseconds
+int itcv_profile_get(int i, int* code, double* flop, float* ms) {
+  if (i < 0 || i >= (int)itcv::g_prof.size()) return itcv::fail("%s: index out of range", "itcv_profile_get");
+  const auto& r = itcv::g_prof[i];
+  *code = r.code;
+  *flop = r.flop;
+  if (hipEventElapsedTime(ms, r.start, r.stop) != hipSuccess) *ms = -1.f;
+  return 0;
+}
+int itcv_profile_clear(void) {
+  for (auto& r : itcv::g_prof) {
+    (void)hipEventDestroy(r.start);
+    (void)hipEventDestroy(r.stop);
+  }
+  itcv::g_prof.clear();
+  return 0;
+}
 }

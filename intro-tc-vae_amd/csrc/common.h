@@ -74,4 +74,15 @@ __device__ __forceinline__ float buf_load(__amdgpu_buffer_rsrc_t r, uint32_t byt
 }
 constexpr uint32_t kOOB = 0xFFFFFFFFu;
 
+// ---- optional per-launch timing of the GEMM-class kernels (bench.py's roofline leg) ------------
+// When enabled, a HIP event pair is recorded on the launch stream immediately around the MAIN kernel
+// of a conv call (not its split-K reduce), tagged with the kernel family / template parameters and the
+// algorithmic FLOP of the launch.  Off by default; never used under graph capture.
+struct ProfScope {
+  hipStream_t st;
+  int slot;
+  ProfScope(hipStream_t stream, int kind, int ks, int bm, int up2, int ns, double flop);
+  ~ProfScope();
+};
+
 }  // namespace itcv

@@ -1073,12 +1073,15 @@ int itcv_conv2d_fwd(const float* x, const float* wp, const float* bias, float* y
   a.x_bytes = (uint32_t)((size_t)B * Ci * (up2 ? (H / 2) * (W / 2) : H * W) * sizeof(float));
   a.slab_stride = p.splits > 1 ? out_elems : 0;
   hipStream_t st = S(stream);
-  if (KS == 1)
-    launch_fwd<1>(a, p.bm, p.splits, up2, st);
-  else if (KS == 3)
-    launch_fwd<3>(a, p.bm, p.splits, up2, st);
-  else
-    launch_fwd<5>(a, p.bm, p.splits, up2, st);
+  {
+    ProfScope prof(st, 0, KS, p.bm, up2 ? 1 : 0, 0, 2.0 * B * H * W * (double)Co * Ci * KS * KS);
+    if (KS == 1)
+      launch_fwd<1>(a, p.bm, p.splits, up2, st);
+    else if (KS == 3)
+      launch_fwd<3>(a, p.bm, p.splits, up2, st);
+    else
+      launch_fwd<5>(a, p.bm, p.splits, up2, st);
+  }
   ITCV_CHECK_LAUNCH("itcv_conv2d_fwd");
   if (p.splits > 1) {
     const int blocks = (int)(cdivz(out_elems, 256) < 2048 ? cdivz(out_elems, 256) : 2048);
@@ -1148,12 +1151,15 @@ int itcv_conv2d_fwd_bf16s(const float* x, const void* wp, const float* bias, flo
   a.x_bytes = (uint32_t)((size_t)B * Ci * (up2 ? (H / 2) * (W / 2) : H * W) * sizeof(float));
   a.slab_stride = p.splits > 1 ? out_elems : 0;
   hipStream_t st = S(stream);
-  if (KS == 1) {
-    if (ns == 2) launch_fwd_b<1, 2>(a, p.bm, p.splits, up2, st);
-    else launch_fwd_b<1, 3>(a, p.bm, p.splits, up2, st);
-  } else {
-    if (ns == 2) launch_fwd_b<3, 2>(a, p.bm, p.splits, up2, st);
-    else launch_fwd_b<3, 3>(a, p.bm, p.splits, up2, st);
+  {
+    ProfScope prof(st, 1, KS, p.bm, up2 ? 1 : 0, ns, 2.0 * B * H * W * (double)Co * Ci * KS * KS);
+    if (KS == 1) {
+      if (ns == 2) launch_fwd_b<1, 2>(a, p.bm, p.splits, up2, st);
+      else launch_fwd_b<1, 3>(a, p.bm, p.splits, up2, st);
+    } else {
+      if (ns == 2) launch_fwd_b<3, 2>(a, p.bm, p.splits, up2, st);
+      else launch_fwd_b<3, 3>(a, p.bm, p.splits, up2, st);
+    }
   }
   ITCV_CHECK_LAUNCH("itcv_conv2d_fwd_bf16s");
   if (p.splits > 1) {
@@ -1195,12 +1201,15 @@ int itcv_conv2d_wgrad(const float* x, const float* dy, float* dw, int B, int Ci,
   a.dy_bytes = (uint32_t)((size_t)B * Co * H * W * sizeof(float));
   a.slab_stride = slab;
   hipStream_t st = S(stream);
-  if (KS == 1)
-    launch_wgrad<1>(a, p.bm, p.cb, up2, st);
-  else if (KS == 3)
-    launch_wgrad<3>(a, p.bm, p.cb, up2, st);
-  else
-    launch_wgrad<5>(a, p.bm, p.cb, up2, st);
+  {
+    ProfScope prof(st, 2, KS, p.bm, up2 ? 1 : 0, 0, 2.0 * B * H * W * (double)Co * Ci * KS * KS);
+    if (KS == 1)
+      launch_wgrad<1>(a, p.bm, p.cb, up2, st);
+    else if (KS == 3)
+      launch_wgrad<3>(a, p.bm, p.cb, up2, st);
+    else
+      launch_wgrad<5>(a, p.bm, p.cb, up2, st);
+  }
   ITCV_CHECK_LAUNCH("itcv_conv2d_wgrad");
   const size_t dw_elems = (size_t)Co * Ci * KS * KS;
   const int blocks = (int)(cdivz(dw_elems, 256) < 2048 ? cdivz(dw_elems, 256) : 2048);
@@ -1242,12 +1251,15 @@ int itcv_conv2d_wgrad_bf16s(const float* x, const float* dy, float* dw, int B, i
   a.dy_bytes = (uint32_t)((size_t)B * Co * H * W * sizeof(float));
   a.slab_stride = slab;
   hipStream_t st = S(stream);
-  if (KS == 1) {
-    if (ns == 2) launch_wgrad_b<1, 2>(a, p.bm, p.cb, st);
-    else launch_wgrad_b<1, 3>(a, p.bm, p.cb, st);
-  } else {
-    if (ns == 2) launch_wgrad_b<3, 2>(a, p.bm, p.cb, st);
-    else launch_wgrad_b<3, 3>(a, p.bm, p.cb, st);
+  {
+    ProfScope prof(st, 3, KS, p.bm, 0, ns, 2.0 * B * H * W * (double)Co * Ci * KS * KS);
+    if (KS == 1) {
+      if (ns == 2) launch_wgrad_b<1, 2>(a, p.bm, p.cb, st);
+      else launch_wgrad_b<1, 3>(a, p.bm, p.cb, st);
+    } else {
+      if (ns == 2) launch_wgrad_b<3, 2>(a, p.bm, p.cb, st);
+      else launch_wgrad_b<3, 3>(a, p.bm, p.cb, st);
+    }
   }
   ITCV_CHECK_LAUNCH("itcv_conv2d_wgrad_bf16s");
   const size_t dw_elems = (size_t)Co * Ci * KS * KS;

@@ -154,10 +154,13 @@ int itcv_conv2d_small_cout_fwd(const float* x, const float* w, const float* bias
     else if (Co == 3) ITCV_SMALL(KS_, 3);     \
     else ITCV_SMALL(KS_, 4);                  \
   } while (0)
-  if (KS == 3)
-    ITCV_SMALL_KS(3);
-  else
-    ITCV_SMALL_KS(5);
+  {
+    ProfScope prof(st, 4, KS, Co, 0, 0, 2.0 * B * H * W * (double)Co * C * KS * KS);
+    if (KS == 3)
+      ITCV_SMALL_KS(3);
+    else
+      ITCV_SMALL_KS(5);
+  }
 #undef ITCV_SMALL_KS
 #undef ITCV_SMALL
   ITCV_CHECK_LAUNCH("itcv_conv2d_small_cout_fwd");
@@ -192,10 +195,13 @@ int itcv_conv2d_small_cin_fwd(const float* x, const float* w, const float* bias,
     else if (C == 3) ITCV_SCIN(KS_, 3);   \
     else ITCV_SCIN(KS_, 4);               \
   } while (0)
-  if (KS == 3)
-    ITCV_SCIN_KS(3);
-  else
-    ITCV_SCIN_KS(5);
+  {
+    ProfScope prof(st, 5, KS, C, 0, 0, 2.0 * B * H * W * (double)Co * C * KS * KS);
+    if (KS == 3)
+      ITCV_SCIN_KS(3);
+    else
+      ITCV_SCIN_KS(5);
+  }
 #undef ITCV_SCIN_KS
 #undef ITCV_SCIN
   ITCV_CHECK_LAUNCH("itcv_conv2d_small_cin_fwd");

@@ -131,21 +131,16 @@ def conv_apply(x, weight, w4, for_dgrad, bias, B, Ci, H, W, Co, KS, up2):
         # <= 4 output channels: direct fp32 conv on the vector ALUs, reads the raw OIHW weights
         y = torch.empty((B, Co, H, W), dtype=F32, device=x.device)
 
-        def launch_small():
-            call("itcv_conv2d_small_cout_fwd", ptr(x), ptr(w4), ptr(bias), ptr(y), B, Ci, H, W, Co, KS, int(for_dgrad),
-                 stream())
-            return y
-        return _profiled_label(f"conv_small_cout_kernel<KS={KS},CO={Co}>", 2.0 * B * H * W * Co * Ci * KS * KS,
-                               launch_small)
+        call("itcv_conv2d_small_cout_fwd", ptr(x), ptr(w4), ptr(bias), ptr(y), B, Ci, H, W, Co, KS, int(for_dgrad),
+             stream())
+        return y
     if not up2 and lib.itcv_conv2d_small_cin_supported(Ci, KS):
         # <= 4 reduction channels: direct fp32 conv, the pixel's input window lives in registers
         y = torch.empty((B, Co, H, W), dtype=F32, device=x.device)
 
-        def launch_scin():
-            call("itcv_conv2d_small_cin_fwd", ptr(x), ptr(w4), ptr(bias), ptr(y), B, Ci, H, W, Co, KS, int(for_dgrad),
-                 stream())
-            return y
-        return _profiled_label(f"conv_small_cin_kernel<KS={KS},CI={Ci}>", 2.0 * B * H * W * Co * Ci * KS * KS, launch_scin)
+        call("itcv_conv2d_small_cin_fwd", ptr(x), ptr(w4), ptr(bias), ptr(y), B, Ci, H, W, Co, KS, int(for_dgrad),
+             stream())
+        return y
     ns = _NS[_CONV_MATH[0]]
     if ns and lib.itcv_conv2d_bf16s_supported(Ci, Co, KS):
         wp = packed_weight(weight, w4, for_dgrad, ns)
@@ -153,18 +148,8 @@ def conv_apply(x, weight, w4, for_dgrad, bias, B, Ci, H, W, Co, KS, up2):
         nws = lib.itcv_conv2d_fwd_bf16s_workspace(B, Ci, H, W, Co, KS)
         ws = _ws(nws, x.device) if nws else None
 
-        def launch():
-            call("itcv_conv2d_fwd_bf16s", ptr(x), ptr(wp), ptr(bias), ptr(y), B, Ci, H, W, Co, KS, int(up2), ns,
-                 ptr(ws), nws, stream())
-            return y
-        if LaunchProfile.active is None:
-            return launch()
-        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        s.record()
-        launch()
-        e.record()
-        LaunchProfile.active.append((f"conv_fwd_bf16s_kernel<KS={KS},BM={64 if Co <= 64 else 128},up2={int(up2)},"
-                                     f"NS={ns}>", 2.0 * B * H * W * Co * Ci * KS * KS, s, e))
+        call("itcv_conv2d_fwd_bf16s", ptr(x), ptr(wp), ptr(bias), ptr(y), B, Ci, H, W, Co, KS, int(up2), ns, ptr(ws), nws,
+             stream())
         return y
     return conv_fwd_raw(x, packed_weight(weight, w4, for_dgrad), bias, B, Ci, H, W, Co, KS, up2)
 
@@ -178,44 +163,35 @@ def pack_weight(w4, for_dgrad):
 
 
 class LaunchProfile:
-    """Optional HIP-event bracket around every implicit-GEMM launch (bench.py's roofline leg).
-    Events are recorded on the stream the kernel is launched on (torch's current stream)."""
-    active = None  # list of (kernel label, algorithmic flop, start event, end event)
+    """Per-launch timing of the GEMM-class kernels, recorded INSIDE libitcv_hip.so: a HIP event pair on
+    the launch stream around the main kernel of every conv call (bench.py's roofline leg)."""
+    KINDS = {0: "conv_fwd_kernel", 1: "conv_fwd_bf16s_kernel", 2: "conv_wgrad_kernel", 3: "conv_wgrad_bf16s_kernel",
+             4: "conv_small_cout_kernel", 5: "conv_small_cin_kernel"}
 
     @classmethod
     def begin(cls):
-        cls.active = []
+        call("itcv_profile_begin")
 
     @classmethod
     def end(cls):
-        rec, cls.active = cls.active, None
-        return rec
-
-
-def _label(kind, v):
-    return f"conv_{kind}_kernel<KS={(v >> 8) & 255},BM={v & 255},up2={(v >> 16) & 1}>/splitK={v >> 20}"
-
-
-def _profiled_label(label, flop, launch):
-    if LaunchProfile.active is None:
-        return launch()
-    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    s.record()
-    out = launch()
-    e.record()
-    LaunchProfile.active.append((label, flop, s, e))
-    return out
-
-
-def _profiled(kind, variant, flop, launch):
-    if LaunchProfile.active is None:
-        return launch()
-    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    s.record()
-    out = launch()
-    e.record()
-    LaunchProfile.active.append((_label(kind, variant), flop, s, e))
-    return out
+        """-> list of (kernel label, algorithmic FLOP, seconds)."""
+        import ctypes
+        n = lib.itcv_profile_end()
+        code, flop, ms = ctypes.c_int(), ctypes.c_double(), ctypes.c_float()
+        out = []
+        for i in range(n):
+            call("itcv_profile_get", i, ctypes.byref(code), ctypes.byref(flop), ctypes.byref(ms))
+            c = code.value
+            kind, ks, bm, up2, ns = c & 15, (c >> 4) & 15, (c >> 8) & 255, (c >> 16) & 1, (c >> 20) & 15
+            if kind in (0, 2):
+                label = f"{cls.KINDS[kind]}<KS={ks},BM={bm},up2={up2}>"
+            elif kind in (1, 3):
+                label = f"{cls.KINDS[kind]}<KS={ks},BM={bm},up2={up2},NS={ns}>"
+            else:
+                label = f"{cls.KINDS[kind]}<KS={ks},C={bm}>"
+            out.append((label, flop.value, ms.value * 1e-3))
+        call("itcv_profile_clear")
+        return out
 
 
 def conv_fwd_raw(x, wp, bias, B, Ci, H, W, Co, KS, up2):
@@ -223,13 +199,8 @@ def conv_fwd_raw(x, wp, bias, B, Ci, H, W, Co, KS, up2):
     nws = lib.itcv_conv2d_fwd_workspace(B, Ci, H, W, Co, KS)
     ws = _ws(nws, x.device) if nws else None
 
-    def launch():
-        call("itcv_conv2d_fwd", ptr(x), ptr(wp), ptr(bias), ptr(y), B, Ci, H, W, Co, KS, int(up2), ptr(ws), nws, stream())
-        return y
-    if LaunchProfile.active is None:
-        return launch()
-    return _profiled("fwd", lib.itcv_conv2d_fwd_variant(B, Ci, H, W, Co, KS, int(up2)),
-                     2.0 * B * H * W * Co * Ci * KS * KS, launch)
+    call("itcv_conv2d_fwd", ptr(x), ptr(wp), ptr(bias), ptr(y), B, Ci, H, W, Co, KS, int(up2), ptr(ws), nws, stream())
+    return y
 
 
 def conv_wgrad_raw(x, dy, B, Ci, H, W, Co, KS, up2, out=None, accumulate=False):
@@ -243,28 +214,13 @@ def conv_wgrad_raw(x, dy, B, Ci, H, W, Co, KS, up2, out=None, accumulate=False):
             call("itcv_upsample2_fwd", ptr(x), ptr(xu), B * Ci, H // 2, W // 2, stream())
             x = xu
 
-        def launch_b():
-            call("itcv_conv2d_wgrad_bf16s", ptr(x), ptr(dy), ptr(dw), B, Ci, H, W, Co, KS, ns, int(accumulate),
-                 ptr(ws), nws, stream())
-            return dw
-        if LaunchProfile.active is None:
-            return launch_b()
-        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        s.record()
-        launch_b()
-        e.record()
-        LaunchProfile.active.append((f"conv_wgrad_bf16s_kernel<KS={KS},BM={64 if Co <= 64 else 128},NS={ns}>+reduce",
-                                     2.0 * B * H * W * Co * Ci * KS * KS, s, e))
+        call("itcv_conv2d_wgrad_bf16s", ptr(x), ptr(dy), ptr(dw), B, Ci, H, W, Co, KS, ns, int(accumulate), ptr(ws), nws,
+             stream())
         return dw
 
-    def launch():
-        call("itcv_conv2d_wgrad", ptr(x), ptr(dy), ptr(dw), B, Ci, H, W, Co, KS, int(up2), int(accumulate), ptr(ws),
-             nws, stream())
-        return dw
-    if LaunchProfile.active is None:
-        return launch()
-    return _profiled("wgrad", lib.itcv_conv2d_wgrad_variant(B, Ci, H, W, Co, KS, int(up2)),
-                     2.0 * B * H * W * Co * Ci * KS * KS, launch)
+    call("itcv_conv2d_wgrad", ptr(x), ptr(dy), ptr(dw), B, Ci, H, W, Co, KS, int(up2), int(accumulate), ptr(ws), nws,
+         stream())
+    return dw
 
 
 def bias_grad_raw(dy, B, C, HW, target=None):
