@@ -172,14 +172,17 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_fwd_kernel(ConvArgs a) {
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   if (kt0 < kt1) {
-    int tap = kt0 / a.cpt, cib = kt0 - tap * a.cpt;
+    // K-tiles run channel-block outer, tap inner: the KS*KS shifted windows of one channel block are
+    // gathered back to back and hit the vector L1 instead of re-reading the planes from L2 per tap
+    constexpr int KKc = KS * KS;
+    int cib = kt0 / KKc, tap = kt0 - cib * KKc;
     load_tile(kt0, tap, cib);
     store_tile(0);
     __syncthreads();
     int cur = 0;
     for (int kt = kt0; kt < kt1; ++kt) {
       const bool more = kt + 1 < kt1;
-      if (++cib == a.cpt) cib = 0, ++tap;
+      if (++tap == KKc) tap = 0, ++cib;
       if (more) load_tile(kt + 1, tap, cib);
       mfma_tile<BK, PA, PB, TM, TN>(&As[cur][half * PA + wm * WTM + l31], &Bs[cur][half * PB + wn * WTN + l31], acc);
       if (more) store_tile(cur ^ 1);
@@ -223,13 +226,14 @@ __global__ void splitk_reduce_fwd(const float* __restrict__ slab, const float* _
   }
 }
 
-// wp[(tap*Cip + c)][m]; for_dgrad swaps the channel roles and flips the taps
+// wp[k][m] with k = ((c/16)*KK + tap)*16 + c%16 (16-channel block outer, tap inner); for_dgrad swaps the
+// channel roles and flips the taps
 __global__ void pack_weight_kernel(const float* __restrict__ w, float* __restrict__ wp, int Co, int Ci, int KK,
                                    int for_dgrad, int C, int M, int Cip, int Mp) {
   const size_t total = (size_t)KK * Cip * Mp;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
     const int k = (int)(i / Mp), m = (int)(i - (size_t)k * Mp);
-    const int tap = k / Cip, c = k - tap * Cip;
+    const int kt = k >> 4, cib = kt / KK, tap = kt - cib * KK, c = cib * 16 + (k & 15);
     float v = 0.f;
     if (c < C && m < M)
       v = for_dgrad ? w[((size_t)c * Ci + m) * KK + (KK - 1 - tap)] : w[((size_t)m * Ci + c) * KK + tap];
@@ -262,6 +266,7 @@ struct ConvArgsB {
   int ktiles, ktiles_per_split, cpt;  // cpt = K-tiles per tap = Cip/32
   uint32_t x_bytes;
   size_t slab_stride;
+  int ablate;  // diagnostic only (ITCV_ABLATE): 1 no gathers, 2 no split, 4 no weight DMA, 8 no MFMA, 16 no B stores
 };
 
 template <int NS>
@@ -286,8 +291,9 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_fwd_bf16s_kernel(ConvArgsB a
   constexpr int NT = WM * WN * 64, BK = 32, KC = BK / 8, P = KS / 2;
   constexpr int WTM = BM / WM, WTN = BN / WN, TM = WTM / 32, TN = WTN / 32;
   static_assert(NT == 256 && (BN == 128 || BN == 256), "loader mapping");
-  __shared__ u32x4 As[NS * KC * BM];
-  __shared__ u32x4 Bs[NS * KC * BN];
+  constexpr int ASZ = NS * KC * BM, BSZ = NS * KC * BN;
+  __shared__ u32x4 As[2 * ASZ];
+  __shared__ u32x4 Bs[2 * BSZ];
 
   const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
   const int wm = wid / WN, wn = wid % WN, l31 = lane & 31, half = lane >> 5;
@@ -326,18 +332,23 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_fwd_bf16s_kernel(ConvArgsB a
   const uint32_t hw4 = (uint32_t)HWs * 4u, row0_4 = (uint32_t)(kg * RPT) * hw4;
 
   constexpr int AV = NS * KC * BM, AL = AV / NT;   // 16-byte chunks of the A tile per thread
-  static_assert(AV % NT == 0, "A tile chunks must divide evenly");
-  u32x4 areg[AL];
+  static_assert(AV % NT == 0 && BM % 64 == 0, "A tile chunks must divide evenly, one wave stays inside a row block");
   float breg[RPT];
 
-  auto load_tile = [&](int kt, int tap, int cib) {
-    // packed weights: [kt][plane][kc][Mp] chunks; this tile's chunks for rows m0..m0+BM-1
+  // A tile (pre-split weights, already in LDS order): LDS-DMA straight from global memory, no VGPR
+  // staging and no ds_write -- the LDS store path (~79 B/clk/CU) is what this kernel is bound by.
+  auto dma_A = [&](int kt, int buf) {
     const u32x4* wt = a.wp + (size_t)kt * NS * KC * a.Mp;
 #pragma unroll
     for (int i = 0; i < AL; ++i) {
       const int idx = t + i * NT, pk = idx / BM, ml = idx - pk * BM;   // pk = plane*KC + kc
-      areg[i] = wt[(size_t)pk * a.Mp + m0 + ml];
+      const int wave_chunk = __builtin_amdgcn_readfirstlane((t & ~63) + i * NT);
+      __builtin_amdgcn_global_load_lds(
+          (const __attribute__((address_space(1))) void*)(wt + (size_t)pk * a.Mp + m0 + ml),
+          (__attribute__((address_space(3))) void*)(As + buf * ASZ + wave_chunk), 16, 0, 0);
     }
+  };
+  auto load_tile = [&](int kt, int tap, int cib) {
     const int dh = tap / KS - P, dw = tap - (tap / KS) * KS - P;
     const bool valid = (tapmask >> tap) & 1u;
     int off;
@@ -349,9 +360,8 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_fwd_bf16s_kernel(ConvArgsB a
 #pragma unroll
     for (int i = 0; i < RPT; ++i) breg[i] = buf_load_s(rx, voff, row0_4 + (uint32_t)i * hw4);
   };
-  auto store_tile = [&]() {
-#pragma unroll
-    for (int i = 0; i < AL; ++i) As[t + i * NT] = areg[i];
+  auto store_tile = [&](int buf) {
+    u32x4* Bd = Bs + buf * BSZ;
 #pragma unroll
     for (int c = 0; c < RPT / 8; ++c) {
       float v[8];
@@ -361,7 +371,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_fwd_bf16s_kernel(ConvArgsB a
       split8<NS>(v, pl);
       const int kc = kg * (RPT / 8) + c;
 #pragma unroll
-      for (int p = 0; p < NS; ++p) Bs[(p * KC + kc) * BN + nl] = pl[p];
+      for (int p = 0; p < NS; ++p) Bd[(p * KC + kc) * BN + nl] = pl[p];
     }
   };
 
@@ -373,51 +383,65 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_fwd_bf16s_kernel(ConvArgsB a
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  auto mfma_step = [&]() {
+  auto mfma_ks = [&](int buf, int ks) {
+    const u32x4* Ab = As + buf * ASZ;
+    const u32x4* Bb = Bs + buf * BSZ;
+    const int kc = ks * 2 + half;
+    bf16x8 af[NS][TM], bfr[NS][TN];
 #pragma unroll
-    for (int ks = 0; ks < BK / 16; ++ks) {
-      const int kc = ks * 2 + half;
-      bf16x8 af[NS][TM], bfr[NS][TN];
-#pragma unroll
-      for (int p = 0; p < NS; ++p) {
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-          af[p][i] = __builtin_bit_cast(bf16x8, As[(p * KC + kc) * BM + wm * WTM + i * 32 + l31]);
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-          bfr[p][j] = __builtin_bit_cast(bf16x8, Bs[(p * KC + kc) * BN + wn * WTN + j * 32 + l31]);
-      }
+    for (int p = 0; p < NS; ++p) {
 #pragma unroll
       for (int i = 0; i < TM; ++i)
+        af[p][i] = __builtin_bit_cast(bf16x8, Ab[(p * KC + kc) * BM + wm * WTM + i * 32 + l31]);
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-          f32x16 c = acc[i][j];
-          if constexpr (NS == 3) {   // smallest terms first
-            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][i], bfr[1][j], c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bfr[2][j], c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2][i], bfr[0][j], c, 0, 0, 0);
-          }
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bfr[1][j], c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][i], bfr[0][j], c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bfr[0][j], c, 0, 0, 0);
-          acc[i][j] = c;
-        }
+      for (int j = 0; j < TN; ++j)
+        bfr[p][j] = __builtin_bit_cast(bf16x8, Bb[(p * KC + kc) * BN + wn * WTN + j * 32 + l31]);
     }
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        f32x16 c = acc[i][j];
+        if constexpr (NS == 3) {   // smallest terms first
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][i], bfr[1][j], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bfr[2][j], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2][i], bfr[0][j], c, 0, 0, 0);
+        }
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bfr[1][j], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][i], bfr[0][j], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bfr[0][j], c, 0, 0, 0);
+        acc[i][j] = c;
+      }
   };
 
+  // Pipeline over K-tiles (two LDS buffers): iteration i computes tile i from LDS[cur] while
+  //   - the split + store of the im2col tile i+1 (gathered into registers during iteration i-1),
+  //   - the LDS-DMA of the weight tile i+1, and
+  //   - the global gather of im2col tile i+2
+  // are issued ahead of its MFMAs, so all memory traffic has the whole MFMA phase to land.  Past the
+  // end the gathers are range-checked to 0 and the unused stores are harmless: no branches in the loop.
   if (kt0 < kt1) {
-    int tap = kt0 / a.cpt, cib = kt0 - tap * a.cpt;
+    constexpr int KKc = KS * KS;   // channel-block outer, tap inner (vector-L1 reuse of the shifted windows)
+    int cib = kt0 / KKc, tap = kt0 - cib * KKc;
+    auto advance = [&]() {
+      if (++tap == KKc) tap = 0, ++cib;
+    };
+    dma_A(kt0, 0);
     load_tile(kt0, tap, cib);
-    store_tile();
+    store_tile(0);
+    advance();
+    load_tile(min(kt0 + 1, kt1 - 1), tap, cib);
     __syncthreads();
+    int cur = 0;
     for (int kt = kt0; kt < kt1; ++kt) {
-      const bool more = kt + 1 < kt1;
-      if (++cib == a.cpt) cib = 0, ++tap;
-      if (more) load_tile(kt + 1, tap, cib);
-      mfma_step();
+      store_tile(cur ^ 1);                            // im2col tile kt+1: registers -> LDS
+      dma_A(min(kt + 1, kt1 - 1), cur ^ 1);           // weight tile kt+1: global -> LDS
+      advance();
+      load_tile(min(kt + 2, kt1 - 1), tap, cib);      // im2col tile kt+2: global -> registers
+      mfma_ks(cur, 0);
+      mfma_ks(cur, 1);
       __syncthreads();
-      if (more) store_tile();
-      __syncthreads();
+      cur ^= 1;
     }
   }
 
@@ -443,7 +467,231 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_fwd_bf16s_kernel(ConvArgsB a
   }
 }
 
-// wp[kt = tap*cpt + cib][plane][kc][Mp] 16-byte chunks of 8 bf16: channels cib*32 + kc*8 + j
+// Wave-specialised form of conv_fwd_bf16s_kernel: 512 threads = 4 consumer waves (one per SIMD) that
+// only read fragments and issue MFMAs + 4 producer waves that only gather / split / store the next
+// tiles.  Two identical 4-wave blocks sharing a SIMD run in lockstep (same program, same barriers): they
+// collide on the matrix pipe and then idle together (measured: 36 % MFMA busy, 42 % issue stalls).  A
+// producer wave next to a consumer wave uses the VALU / VMEM / LDS-store paths while the matrix pipe
+// of the same SIMD stays fed.
+template <int KS, int BM, int BN, int WM, int WN, bool UP2, int NS>
+__global__ __launch_bounds__(512) void conv_fwd_bf16s_ws_kernel(ConvArgsB a) {
+  constexpr int NP = 256, BK = 32, KC = BK / 8, P = KS / 2, KKc = KS * KS;
+  constexpr int WTM = BM / WM, WTN = BN / WN, TM = WTM / 32, TN = WTN / 32;
+  static_assert(WM * WN == 4 && (BN == 128 || BN == 256) && BM % 64 == 0, "tile / wave layout");
+  constexpr int ASZ = NS * KC * BM, BSZ = NS * KC * BN;
+  __shared__ u32x4 As[2 * ASZ];
+  __shared__ u32x4 Bs[2 * BSZ];
+
+  const int t = threadIdx.x, lane = t & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int bid = blockIdx.x, xcd = bid & 7, q = bid >> 3;
+  const int tile_m = q % a.mt, tile_n = (q / a.mt) * 8 + xcd;
+  if (tile_n >= a.nt) return;
+  const int sk = blockIdx.y;
+  const int kt0 = sk * a.ktiles_per_split;
+  const int kt1 = min(a.ktiles, kt0 + a.ktiles_per_split);
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int H = a.H, W = a.W, HW = H * W;
+  const int nk = kt1 - kt0;
+  if (nk <= 0) return;
+
+  if (wid >= 4) {
+    // ------------------------------------------------------------------ producers
+    const int p = t - 256;
+    const int Hs = UP2 ? H / 2 : H, Ws = UP2 ? W / 2 : W, HWs = Hs * Ws;
+    constexpr int BROWS = NP / BN, RPT = BK / BROWS;
+    const int nl = p % BN;
+    const int kg = __builtin_amdgcn_readfirstlane(p / BN);
+    const int n = n0 + nl;
+    const bool nvalid = n < a.N;
+    int bi = 0, h = 0, w = 0;
+    if (nvalid) {
+      bi = n / HW;
+      const int hw = n - bi * HW;
+      h = hw / W;
+      w = hw - h * W;
+    }
+    uint32_t tapmask = 0;
+#pragma unroll
+    for (int tap = 0; tap < KKc; ++tap) {
+      const int dh = tap / KS - P, dw = tap % KS - P;
+      if (nvalid && (unsigned)(h + dh) < (unsigned)H && (unsigned)(w + dw) < (unsigned)W) tapmask |= 1u << tap;
+    }
+    const int tb = bi * a.Ci * HWs + (UP2 ? 0 : h * W + w);
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(a.x, a.x_bytes);
+    const uint32_t hw4 = (uint32_t)HWs * 4u, row0_4 = (uint32_t)(kg * RPT) * hw4;
+    constexpr int DEPTH = 3;                 // gathers run DEPTH-1 tiles ahead of the tile being stored
+    float breg[DEPTH][RPT];
+
+    auto load_B = [&](float (&dst)[RPT], int tap, int cib) {
+      const int dh = tap / KS - P, dw = tap - (tap / KS) * KS - P;
+      const bool valid = (tapmask >> tap) & 1u;
+      int off;
+      if (UP2)
+        off = tb + ((h + dh) >> 1) * Ws + ((w + dw) >> 1) + cib * BK * HWs;
+      else
+        off = tb + dh * W + dw + cib * BK * HWs;
+      const uint32_t voff = valid ? (uint32_t)off * 4u : kOobBase;
+      if (a.ablate & 1) {
+#pragma unroll
+        for (int i = 0; i < RPT; ++i) dst[i] = __builtin_bit_cast(float, voff + i);
+        return;
+      }
+#pragma unroll
+      for (int i = 0; i < RPT; ++i) dst[i] = buf_load_s(rx, voff, row0_4 + (uint32_t)i * hw4);
+    };
+    auto store_B = [&](const float (&src)[RPT], int buf) {
+      u32x4* Bd = Bs + buf * BSZ;
+#pragma unroll
+      for (int c = 0; c < RPT / 8; ++c) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = src[c * 8 + j];
+        u32x4 pl[NS];
+        if (a.ablate & 2) {
+#pragma unroll
+          for (int pp = 0; pp < NS; ++pp)
+            pl[pp] = u32x4{__builtin_bit_cast(unsigned, v[pp]), __builtin_bit_cast(unsigned, v[2 + pp]),
+                           __builtin_bit_cast(unsigned, v[4 + pp]), __builtin_bit_cast(unsigned, v[6 + (pp & 1)])};
+        } else {
+          split8<NS>(v, pl);
+        }
+        const int kc = kg * (RPT / 8) + c;
+        if (a.ablate & 16) {
+          asm volatile("" ::"v"(pl[0][0]), "v"(pl[NS - 1][3]));
+          continue;
+        }
+#pragma unroll
+        for (int pp = 0; pp < NS; ++pp) Bd[(pp * KC + kc) * BN + nl] = pl[pp];
+      }
+    };
+    int cib = kt0 / KKc, tap = kt0 - cib * KKc;
+    auto advance = [&]() {
+      if (++tap == KKc) tap = 0, ++cib;
+    };
+    // prologue: tile 0 -> LDS[0]; tiles 1 .. DEPTH-1 in flight (past the end the tap mask / hardware range
+    // check turn the gathers into zeros, so no tail branches)
+    load_B(breg[0], tap, cib);
+    store_B(breg[0], 0);
+#pragma unroll
+    for (int d = 1; d < DEPTH; ++d) {
+      advance();
+      load_B(breg[d % DEPTH], tap, cib);
+    }
+    __syncthreads();
+    int cur = 0;
+    // iteration i: store tile i+1 (ring slot (i+1)%DEPTH), DMA weight tile i+1, gather tile i+DEPTH into the
+    // slot just freed; unrolled by DEPTH so that every ring slot is a fixed register set
+    for (int i0 = 0; i0 < nk; i0 += DEPTH) {
+#pragma unroll
+      for (int u = 0; u < DEPTH; ++u) {
+        const int i = i0 + u;
+        if (i < nk) {
+          store_B(breg[(u + 1) % DEPTH], cur ^ 1);   // tile i+1 lives in ring slot (i+1) % DEPTH
+          advance();
+          load_B(breg[u], tap, cib);                  // tile i+DEPTH -> slot i % DEPTH (tile i's, now free)
+          // publish the stored tile: only the ds_writes must have landed; the gathers stay in flight
+          // across the barrier (vmcnt is per wave and the weight DMA lives in the consumer waves' queue)
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          __builtin_amdgcn_s_barrier();
+          cur ^= 1;
+        }
+      }
+    }
+    return;
+  }
+
+  // -------------------------------------------------------------------- consumers
+  const int wm = wid / WN, wn = wid % WN, l31 = lane & 31, half = lane >> 5;
+  // weight tiles (pre-split, already in LDS order) go global -> LDS by LDS-DMA from the consumer waves:
+  // their vmcnt queue holds nothing else, so draining it at the barrier costs the gathers nothing
+  constexpr int AL = ASZ / NP;
+  static_assert(ASZ % NP == 0, "A tile chunks must divide evenly");
+  auto dma_A = [&](int kt, int buf) {
+    if (a.ablate & 4) return;
+    const u32x4* wt = a.wp + (size_t)kt * NS * KC * a.Mp;
+#pragma unroll
+    for (int i = 0; i < AL; ++i) {
+      const int idx = t + i * NP, pk = idx / BM, ml = idx - pk * BM;
+      const int wave_chunk = __builtin_amdgcn_readfirstlane((t & ~63) + i * NP);
+      __builtin_amdgcn_global_load_lds(
+          (const __attribute__((address_space(1))) void*)(wt + (size_t)pk * a.Mp + m0 + ml),
+          (__attribute__((address_space(3))) void*)(As + buf * ASZ + wave_chunk), 16, 0, 0);
+    }
+  };
+  dma_A(kt0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  __syncthreads();
+  int cur = 0;
+  for (int it = 0; it < nk; ++it) {
+    dma_A(min(kt0 + it + 1, kt1 - 1), cur ^ 1);
+    const u32x4* Ab = As + cur * ASZ;
+    const u32x4* Bb = Bs + cur * BSZ;
+#pragma unroll
+    for (int ks = 0; ks < BK / 16; ++ks) {
+      if (a.ablate & 8) break;
+      const int kc = ks * 2 + half;
+      bf16x8 af[NS][TM], bfr[NS][TN];
+#pragma unroll
+      for (int pp = 0; pp < NS; ++pp) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+          af[pp][i] = __builtin_bit_cast(bf16x8, Ab[(pp * KC + kc) * BM + wm * WTM + i * 32 + l31]);
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          bfr[pp][j] = __builtin_bit_cast(bf16x8, Bb[(pp * KC + kc) * BN + wn * WTN + j * 32 + l31]);
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          f32x16 c = acc[i][j];
+          if constexpr (NS == 3) {
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][i], bfr[1][j], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bfr[2][j], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2][i], bfr[0][j], c, 0, 0, 0);
+          }
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bfr[1][j], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][i], bfr[0][j], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bfr[0][j], c, 0, 0, 0);
+          acc[i][j] = c;
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the weight DMA of tile it+1 has landed
+    __syncthreads();
+    cur ^= 1;
+  }
+
+  float* out = a.y + (size_t)sk * a.slab_stride;
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int nn = n0 + wn * WTN + j * 32 + l31;
+    if (nn >= a.N) continue;
+    const int b2 = nn / HW, hw2 = nn - b2 * HW;
+    const size_t base = (size_t)b2 * a.Co * HW + hw2;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (m < a.Co) {
+          float v = acc[i][j][r];
+          if (a.bias) v += a.bias[m];
+          out[base + (size_t)m * HW] = v;
+        }
+      }
+    }
+  }
+}
+
+// wp[kt = cib*KK + tap][plane][kc][Mp] 16-byte chunks of 8 bf16: channels cib*32 + kc*8 + j
 template <int NS>
 __global__ void pack_weight_bf16s_kernel(const float* __restrict__ w, u32x4* __restrict__ wp, int Co, int Ci, int KK,
                                          int for_dgrad, int C, int M, int cpt, int Mp) {
@@ -452,7 +700,7 @@ __global__ void pack_weight_bf16s_kernel(const float* __restrict__ w, u32x4* __r
     const int m = (int)(i % Mp);
     const size_t r = i / Mp;
     const int kc = (int)(r & 3), kt = (int)(r >> 2);
-    const int tap = kt / cpt, cib = kt - tap * cpt;
+    const int cib = kt / KK, tap = kt - cib * KK;
     float v[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -972,9 +1220,29 @@ static FwdPlanB plan_fwd_b(int B, int Ci, int H, int W, int Co, int KS) {
   return p;
 }
 
+static int bf16s_ws() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("ITCV_BF16S_WS");
+    v = (e && e[0] == '0') ? 0 : 1;
+  }
+  return v;
+}
+
 template <int KS, int NS>
 static void launch_fwd_b(const ConvArgsB& a, int bm, int splits, int up2, hipStream_t st) {
   dim3 grid(cdiv(a.nt, 8) * 8 * a.mt, splits), block(256);
+  if (bf16s_ws()) {
+    dim3 blk(512);
+    if (bm == 64) {
+      if (up2) hipLaunchKernelGGL((conv_fwd_bf16s_ws_kernel<KS, 64, 256, 1, 4, true, NS>), grid, blk, 0, st, a);
+      else hipLaunchKernelGGL((conv_fwd_bf16s_ws_kernel<KS, 64, 256, 1, 4, false, NS>), grid, blk, 0, st, a);
+    } else {
+      if (up2) hipLaunchKernelGGL((conv_fwd_bf16s_ws_kernel<KS, 128, 128, 2, 2, true, NS>), grid, blk, 0, st, a);
+      else hipLaunchKernelGGL((conv_fwd_bf16s_ws_kernel<KS, 128, 128, 2, 2, false, NS>), grid, blk, 0, st, a);
+    }
+    return;
+  }
   if (bm == 64) {
     if (up2) hipLaunchKernelGGL((conv_fwd_bf16s_kernel<KS, 64, 256, 1, 4, true, NS>), grid, block, 0, st, a);
     else hipLaunchKernelGGL((conv_fwd_bf16s_kernel<KS, 64, 256, 1, 4, false, NS>), grid, block, 0, st, a);
@@ -1150,6 +1418,14 @@ int itcv_conv2d_fwd_bf16s(const float* x, const void* wp, const float* bias, flo
   a.mt = p.mt, a.nt = p.nt, a.ktiles = p.ktiles, a.ktiles_per_split = p.kps, a.cpt = p.cip / 32;
   a.x_bytes = (uint32_t)((size_t)B * Ci * (up2 ? (H / 2) * (W / 2) : H * W) * sizeof(float));
   a.slab_stride = p.splits > 1 ? out_elems : 0;
+  {
+    static int abl = -1;
+    if (abl < 0) {
+      const char* e = getenv("ITCV_ABLATE");
+      abl = e ? atoi(e) : 0;
+    }
+    a.ablate = abl;
+  }
   hipStream_t st = S(stream);
   {
     ProfScope prof(st, 1, KS, p.bm, up2 ? 1 : 0, ns, 2.0 * B * H * W * (double)Co * Ci * KS * KS);
