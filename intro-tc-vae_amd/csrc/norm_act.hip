@@ -13,9 +13,20 @@ __device__ __forceinline__ uint32_t fdiv(uint32_t a, uint32_t d, int sh) { retur
 
 // ------------------------------------------------------------------ channel moments (fp64)
 // grid (C, splits): block (c, s) reduces its slice of channel c's B*HW values
+struct BnFinal {   // arguments of the fused single-launch path (splits == 1)
+  double count;
+  float eps, momentum;
+  float* running_mean;
+  float* running_var;
+  int64_t* nbt;
+  float* mean;
+  float* rstd;
+};
+
+template <bool FUSED>
 __global__ __launch_bounds__(kRedThreads) void bn_moments_partial(const float* __restrict__ x,
                                                                   double* __restrict__ part, int B, int C, int HW,
-                                                                  int splits, int hw_shift) {
+                                                                  int splits, int hw_shift, BnFinal f) {
   __shared__ double scratch[kRedThreads / 64];
   const uint32_t c = blockIdx.x, s = blockIdx.y, hw_n = HW, total = (uint32_t)B * hw_n;
   const uint32_t chunk = ((total + splits - 1) / splits + 3) & ~3u;  // multiple of 4: float4 stays aligned
@@ -39,8 +50,22 @@ __global__ __launch_bounds__(kRedThreads) void bn_moments_partial(const float* _
   s1 = block_sum(s1, scratch);
   s2 = block_sum(s2, scratch);
   if (threadIdx.x == 0) {
-    part[((size_t)s * 2 + 0) * C + c] = s1;
-    part[((size_t)s * 2 + 1) * C + c] = s2;
+    if (FUSED) {   // one block owns the whole channel: finalise here, no second launch
+      const double m = s1 / f.count;
+      double var = s2 / f.count - m * m;
+      if (var < 0.0) var = 0.0;
+      f.mean[c] = (float)m;
+      f.rstd[c] = (float)(1.0 / sqrt(var + (double)f.eps));
+      if (f.running_mean) f.running_mean[c] = (1.f - f.momentum) * f.running_mean[c] + f.momentum * (float)m;
+      if (f.running_var) {
+        const double unbiased = f.count > 1.0 ? var * f.count / (f.count - 1.0) : var;
+        f.running_var[c] = (1.f - f.momentum) * f.running_var[c] + f.momentum * (float)unbiased;
+      }
+      if (c == 0 && f.nbt) f.nbt[0] += 1;
+    } else {
+      part[((size_t)s * 2 + 0) * C + c] = s1;
+      part[((size_t)s * 2 + 1) * C + c] = s2;
+    }
   }
 }
 
@@ -260,12 +285,19 @@ __device__ __forceinline__ float4 upstream4(const float* __restrict__ dy, uint32
                      (a1.z + a1.w) + (b1.z + b1.w));
 }
 
-template <int MODE>
+struct BnBwdFinal {   // fused single-launch path (splits == 1): the block writes dsums and the parameter grads
+  double* dsums;
+  float* dgamma;
+  float* dbeta;
+  int accumulate;
+};
+
+template <int MODE, bool FUSED>
 __global__ __launch_bounds__(kRedThreads) void bn_bwd_partial_v4(
     const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ mean,
     const float* __restrict__ rstd, const float* __restrict__ gamma, const float* __restrict__ beta,
     const float* __restrict__ skip, double* __restrict__ part, int B, int C, int H, int W, float slope, int splits,
-    int w_shift, int hw_shift) {
+    int w_shift, int hw_shift, BnBwdFinal f) {
   __shared__ double scratch[kRedThreads / 64];
   const uint32_t c = blockIdx.x, s = blockIdx.y, HW = H * W, total = (uint32_t)B * HW;
   const uint32_t chunk = ((total + splits - 1) / splits + 3) & ~3u;
@@ -295,8 +327,15 @@ __global__ __launch_bounds__(kRedThreads) void bn_bwd_partial_v4(
   s1 = block_sum(s1, scratch);
   s2 = block_sum(s2, scratch);
   if (threadIdx.x == 0) {
-    part[((size_t)s * 2 + 0) * C + c] = s1;
-    part[((size_t)s * 2 + 1) * C + c] = s2;
+    if (FUSED) {
+      f.dsums[c] = s1;
+      f.dsums[C + c] = s2;
+      if (f.dbeta) f.dbeta[c] = (f.accumulate ? f.dbeta[c] : 0.f) + (float)s1;
+      if (f.dgamma) f.dgamma[c] = (f.accumulate ? f.dgamma[c] : 0.f) + (float)s2;
+    } else {
+      part[((size_t)s * 2 + 0) * C + c] = s1;
+      part[((size_t)s * 2 + 1) * C + c] = s2;
+    }
   }
 }
 
@@ -424,7 +463,9 @@ static inline int bn_splits(int B, int C, int HW) {
   const size_t maxs = cdivz(total, 1024);
   if ((size_t)s > maxs) s = (int)maxs;
   if (s < 1) s = 1;
-  // keep every slice a multiple of 4 elements so the float4 path stays aligned
+  // wide layers: one block per channel fills the chip on its own and lets the statistics (and the
+  // backward sums) be finalised in the same launch
+  if (C >= 256 && total <= 65536) s = 1;
   return s;
 }
 
@@ -444,8 +485,8 @@ int itcv_bn_moments(const float* x, double* sums, int B, int C, int HW, void* ws
   const int splits = bn_splits(B, C, HW);
   ITCV_REQUIRE(ws && ws_bytes >= (size_t)splits * 2 * C * sizeof(double), "itcv_bn_moments(workspace)");
   double* part = static_cast<double*>(ws);
-  hipLaunchKernelGGL(bn_moments_partial, dim3(C, splits), dim3(kRedThreads), 0, S(stream), x, part, B, C, HW, splits,
-                     ilog2_exact(HW));
+  hipLaunchKernelGGL(bn_moments_partial<false>, dim3(C, splits), dim3(kRedThreads), 0, S(stream), x, part, B, C, HW,
+                     splits, ilog2_exact(HW), BnFinal{});
   ITCV_CHECK_LAUNCH("itcv_bn_moments");
   hipLaunchKernelGGL(combine_partials, dim3(cdiv(2 * C, 256)), dim3(256), 0, S(stream), part, sums, 2 * C, splits);
   ITCV_CHECK_LAUNCH("itcv_bn_moments(combine)");
@@ -459,8 +500,15 @@ int itcv_bn_train_stats(const float* x, int B, int C, int HW, float eps, float m
   const int splits = bn_splits(B, C, HW);
   ITCV_REQUIRE(ws && ws_bytes >= (size_t)splits * 2 * C * sizeof(double), "itcv_bn_train_stats(workspace)");
   double* part = static_cast<double*>(ws);
-  hipLaunchKernelGGL(bn_moments_partial, dim3(C, splits), dim3(kRedThreads), 0, S(stream), x, part, B, C, HW, splits,
-                     ilog2_exact(HW));
+  if (splits == 1) {
+    const BnFinal f{(double)B * HW, eps, momentum, running_mean, running_var, num_batches_tracked, mean, rstd};
+    hipLaunchKernelGGL(bn_moments_partial<true>, dim3(C, 1), dim3(kRedThreads), 0, S(stream), x, part, B, C, HW, 1,
+                       ilog2_exact(HW), f);
+    ITCV_CHECK_LAUNCH("itcv_bn_train_stats(fused)");
+    return 0;
+  }
+  hipLaunchKernelGGL(bn_moments_partial<false>, dim3(C, splits), dim3(kRedThreads), 0, S(stream), x, part, B, C, HW,
+                     splits, ilog2_exact(HW), BnFinal{});
   ITCV_CHECK_LAUNCH("itcv_bn_train_stats");
   hipLaunchKernelGGL(bn_combine_finalize_kernel, dim3(cdiv(C, 256)), dim3(256), 0, S(stream), part, splits,
                      (double)B * HW, eps, momentum, running_mean, running_var, num_batches_tracked, mean, rstd, C);
@@ -522,9 +570,13 @@ int itcv_bn_act_bwd_reduce(const float* x, const float* dy, const float* mean, c
   hipStream_t st = S(stream);
 #define ITCV_BWD_PARTIAL(MODE)                                                                                   \
   do {                                                                                                           \
-    if (vec)                                                                                                     \
-      hipLaunchKernelGGL(bn_bwd_partial_v4<MODE>, grid, dim3(kRedThreads), 0, st, x, dy, mean, rstd, gamma, beta, \
-                         skip, part, B, C, H, W, slope, splits, wsh, hwsh);                                      \
+    if (vec && splits == 1)                                                                                      \
+      hipLaunchKernelGGL((bn_bwd_partial_v4<MODE, true>), grid, dim3(kRedThreads), 0, st, x, dy, mean, rstd,      \
+                         gamma, beta, skip, part, B, C, H, W, slope, 1, wsh, hwsh,                               \
+                         BnBwdFinal{dsums, dgamma, dbeta, accumulate});                                          \
+    else if (vec)                                                                                                \
+      hipLaunchKernelGGL((bn_bwd_partial_v4<MODE, false>), grid, dim3(kRedThreads), 0, st, x, dy, mean, rstd,     \
+                         gamma, beta, skip, part, B, C, H, W, slope, splits, wsh, hwsh, BnBwdFinal{});           \
     else                                                                                                         \
       hipLaunchKernelGGL(bn_bwd_partial<MODE>, grid, dim3(kRedThreads), 0, st, x, dy, mean, rstd, gamma, beta,    \
                          skip, part, B, C, H, W, slope, splits);                                                 \
@@ -537,6 +589,7 @@ int itcv_bn_act_bwd_reduce(const float* x, const float* dy, const float* mean, c
     ITCV_BWD_PARTIAL(0);
 #undef ITCV_BWD_PARTIAL
   ITCV_CHECK_LAUNCH("itcv_bn_act_bwd_reduce");
+  if (vec && splits == 1) return 0;   // the fused kernel already wrote dsums and the parameter gradients
   hipLaunchKernelGGL(bn_combine_param_kernel, dim3(cdiv(C, 256)), dim3(256), 0, S(stream), part, dsums, C, splits,
                      dgamma, dbeta, accumulate);
   ITCV_CHECK_LAUNCH("itcv_bn_act_bwd_reduce(combine)");

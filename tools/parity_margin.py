@@ -30,6 +30,7 @@ for mode in ("fp32", "bf16x6", "bf16x3"):
     HF.set_conv_math(mode)
     model = fresh().cuda().train()
     s = IntroTCSovler(DS(), model, B, torch.optim.Adam(model.encoder.parameters(), lr=2e-4), torch.optim.Adam(model.decoder.parameters(), lr=2e-4), "mse", 0.5, 0.75, 512.0, 1e-8, torch.device("cuda:0"), False, None, clip=100.0)
+    s.conv_math = mode
     for i, d in enumerate(draws):
         with ops.noise_queue(d):
             got = s.train_step(x, i)
