@@ -199,7 +199,7 @@ def main():
     conv_flop = sum(b[1] for b in buckets.values())
     dom_label, dom = max(buckets.items(), key=lambda kv: kv[1][2])
     achieved = dom[1] / dom[2] * 1e-12
-    if "bf16s" in dom_label:
+    if "bf16s" in dom_label or "bf16p" in dom_label:
         products = 3 if "NS=2" in dom_label else 6
         peak, peak_note = PEAK_BF16_MFMA_TFLOPS / products, f"2500 TFLOP/s dense bf16 MFMA / {products} bf16 products per fp32 product"
     else:

@@ -73,6 +73,16 @@ int itcv_conv2d_pack_weight_bf16s(const float* w, void* wp, int Co, int Ci, int 
 size_t itcv_conv2d_fwd_bf16s_workspace(int B, int Ci, int H, int W, int Co, int KS);
 int itcv_conv2d_fwd_bf16s(const float* x, const void* wp, const float* bias, float* y, int B, int Ci, int H,
                           int W, int Co, int KS, int up2, int ns, void* ws, size_t ws_bytes, void* stream);
+/* Pre-split operand ("planes"): planes[p][b][c/8][h][w] = one 16-byte chunk of 8 bf16 = plane p of
+ * channels c..c+7 of one pixel (C % 8 == 0; p < ns).  A producing pass (itcv_split_planes, or the
+ * BatchNorm apply / backward kernels through their `planes` argument) writes it next to the fp32
+ * tensor; itcv_conv2d_fwd_bf16p then moves both operands global -> LDS by LDS-DMA (no gather, no
+ * conversion in the conv kernel).  Same contract, shapes, workspace and -- bit for bit -- results as
+ * itcv_conv2d_fwd_bf16s (replaces the same ATen conv forward / data-gradient, models.py:28-47). */
+size_t itcv_planes_bytes(int B, int C, int HW, int ns);
+int itcv_split_planes(const float* x, void* planes, int B, int C, int HW, int ns, void* stream);
+int itcv_conv2d_fwd_bf16p(const void* xplanes, const void* wp, const float* bias, float* y, int B, int Ci, int H,
+                          int W, int Co, int KS, int up2, int ns, void* ws, size_t ws_bytes, void* stream);
 /* Direct (vector-ALU, exact fp32) convolution for layers with at most 4 output channels -- the 5x5
  * predict conv 64->3 (models.py:290) and the data-gradient of the 5x5 stem (models.py:213), where a
  * 32-row MFMA tile would be >90 % padding.  for_dgrad = 0: w is [Co][C][KS][KS]; for_dgrad = 1: w is the

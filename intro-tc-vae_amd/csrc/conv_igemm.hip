@@ -255,6 +255,25 @@ __global__ void pack_weight_kernel(const float* __restrict__ w, float* __restric
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
+// LDS-DMA of one 16-byte chunk per lane (global -> LDS at lds_base + lane*16), issued as raw ISA: the
+// compiler's own tracking of the builtin puts an `s_waitcnt vmcnt(0)` in front of EVERY later ds_read
+// (it cannot tell the ring slots apart), which serialises the prefetch with the tile being computed.
+// The caller orders the reads by hand (s_waitcnt vmcnt(N) + barrier).
+#pragma clang diagnostic ignored "-Winline-asm"   // m0 is a reserved register: named so the compiler re-materialises it
+__device__ __forceinline__ void lds_dma16(const void* gptr, uint32_t lds_base) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off"
+               :
+               : "s"(lds_base), "v"(gptr)
+               : "memory", "m0");
+}
+__device__ __forceinline__ uint32_t lds_addr(const void* p) {
+  return (uint32_t)(size_t)(const __attribute__((address_space(3))) void*)p;
+}
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
 struct ConvArgsB {
   const float* x;
   const u32x4* wp;
@@ -614,9 +633,7 @@ __global__ __launch_bounds__(512) void conv_fwd_bf16s_ws_kernel(ConvArgsB a) {
     for (int i = 0; i < AL; ++i) {
       const int idx = t + i * NP, pk = idx / BM, ml = idx - pk * BM;
       const int wave_chunk = __builtin_amdgcn_readfirstlane((t & ~63) + i * NP);
-      __builtin_amdgcn_global_load_lds(
-          (const __attribute__((address_space(1))) void*)(wt + (size_t)pk * a.Mp + m0 + ml),
-          (__attribute__((address_space(3))) void*)(As + buf * ASZ + wave_chunk), 16, 0, 0);
+      lds_dma16(wt + (size_t)pk * a.Mp + m0 + ml, lds_addr(As + buf * ASZ + wave_chunk));
     }
   };
   dma_A(kt0, 0);
@@ -684,10 +701,217 @@ __global__ __launch_bounds__(512) void conv_fwd_bf16s_ws_kernel(ConvArgsB a) {
         if (m < a.Co) {
           float v = acc[i][j][r];
           if (a.bias) v += a.bias[m];
+          if ((a.ablate & 32) && v != 12345.f) continue;
           out[base + (size_t)m * HW] = v;
         }
       }
     }
+  }
+}
+
+// ---------------------------------------------------------------- pre-split ("planes") operand
+// The im2col operand can also arrive ALREADY split: planes[p][b][c/8][h][w] = one 16-byte chunk holding
+// bf16 plane p of channels c..c+7 of one pixel -- exactly one MFMA fragment row.  The producing pass
+// (BatchNorm apply / its backward, or itcv_split_planes) writes it next to the fp32 tensor; the conv
+// kernel then has no gather, no conversion and no ds_write at all: both operands go global -> LDS by
+// LDS-DMA, one 1-KiB piece per wave instruction, issued by four loader waves that run NSTAGE-1 K-tiles
+// ahead of the four MFMA waves (counted vmcnt + one barrier per K-tile).  Padding taps read a zero chunk.
+// Arithmetic (split, product order, K order) is identical to conv_fwd_bf16s_*: results match bit for bit.
+__device__ u32x4 g_zero_chunk = {0u, 0u, 0u, 0u};
+
+struct ConvArgsP {
+  const u32x4* xp;
+  const u32x4* wp;
+  const float* bias;
+  float* y;
+  int B, Ci, H, W, Co;
+  int Mp, N;
+  int mt, nt;
+  int ktiles, ktiles_per_split;
+  size_t slab_stride;
+  size_t plane_stride;   // chunks per plane = B * (Ci/8) * Hs * Ws
+  int ablate;            // diagnostic only (ITCV_ABLATE): 1 no B pieces, 4 no A pieces, 8 no MFMA
+};
+
+template <int KS, int BM, int BN, int WM, int WN, bool UP2, int NS, int NSTAGE>
+__global__ __launch_bounds__(512) void conv_fwd_bf16p_kernel(ConvArgsP a) {
+  constexpr int BK = 32, KC = BK / 8, P = KS / 2, KKc = KS * KS;
+  constexpr int WTM = BM / WM, WTN = BN / WN, TM = WTM / 32, TN = WTN / 32;
+  static_assert(WM * WN == 4 && (BN == 128 || BN == 256) && (BM == 64 || BM == 128), "tile / wave layout");
+  constexpr int ASZ = NS * KC * BM, BSZ = NS * KC * BN, SSZ = ASZ + BSZ;   // 16-byte chunks per stage
+  extern __shared__ u32x4 smem[];
+
+  const int t = threadIdx.x, lane = t & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int bid = blockIdx.x, xcd = bid & 7, q = bid >> 3;
+  const int tile_m = q % a.mt, tile_n = (q / a.mt) * 8 + xcd;
+  if (tile_n >= a.nt) return;
+  const int sk = blockIdx.y;
+  const int kt0 = sk * a.ktiles_per_split;
+  const int kt1 = min(a.ktiles, kt0 + a.ktiles_per_split);
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int H = a.H, W = a.W, HW = H * W;
+  const int nk = kt1 - kt0;
+  if (nk <= 0) return;
+  const uint32_t smem_base = lds_addr(smem);
+
+  if (wid >= 4) {
+    // ------------------------------------------------------------------ loaders
+    const int lw = wid - 4;
+    constexpr int NPA = BM / 64, NPB = BN / 64;            // 1-KiB pieces per (plane, k-chunk) row
+    constexpr int PA = NS * KC * NPA / 4, PB = NS * KC * NPB / 4, PT = PA + PB;   // pieces per wave per tile
+    static_assert((NS * KC * NPA) % 4 == 0 && (NPB == 2 || NPB == 4), "piece split");
+    const int Hs = UP2 ? H / 2 : H, Ws = UP2 ? W / 2 : W, HWs = Hs * Ws;
+    const int C8 = a.Ci >> 3;
+    // this wave's pixel column of the B tile is the same for all of its pieces
+    const int nlc = lw % NPB;
+    const int n = n0 + nlc * 64 + lane;
+    const bool nvalid = n < a.N;
+    int bi = 0, h = 0, w = 0;
+    if (nvalid) {
+      bi = n / HW;
+      const int hw = n - bi * HW;
+      h = hw / W;
+      w = hw - h * W;
+    }
+    uint32_t tapmask = 0;
+#pragma unroll
+    for (int tap = 0; tap < KKc; ++tap) {
+      const int dh = tap / KS - P, dw = tap % KS - P;
+      if (nvalid && (unsigned)(h + dh) < (unsigned)H && (unsigned)(w + dw) < (unsigned)W) tapmask |= 1u << tap;
+    }
+    const long long cb = (long long)bi * C8 * HWs + (UP2 ? 0 : h * W + w);
+    const u32x4* zero = &g_zero_chunk;
+
+    auto issue = [&](int kt, int slot) {
+      const int cib = kt / KKc, tap = kt - cib * KKc;
+      const int dh = tap / KS - P, dw = tap - (tap / KS) * KS - P;
+      const bool valid = (tapmask >> tap) & 1u;
+      const int shift = UP2 ? ((h + dh) >> 1) * Ws + ((w + dw) >> 1) : dh * W + dw;
+      const u32x4* src0 = a.xp + (cb + (long long)(cib * KC) * HWs + shift);
+      const uint32_t sbase = smem_base + (uint32_t)(slot * SSZ) * 16u;
+      const u32x4* wt = a.wp + (size_t)kt * NS * KC * a.Mp + m0 + lane;
+#pragma unroll
+      for (int j = 0; j < PA; ++j) {
+        if (a.ablate & 4) break;
+        const int piece = j * 4 + lw, mlc = piece % NPA, pk = piece / NPA;
+        lds_dma16(wt + (size_t)pk * a.Mp + mlc * 64, sbase + (uint32_t)(pk * BM + mlc * 64) * 16u);
+      }
+#pragma unroll
+      for (int j = 0; j < PB; ++j) {
+        if (a.ablate & 1) break;
+        const int piece = j * 4 + lw, pk = piece / NPB, pl = pk / KC, kc = pk - pl * KC;
+        const u32x4* src = src0 + ((size_t)pl * a.plane_stride + (size_t)kc * HWs);
+        lds_dma16(valid ? src : zero, sbase + (uint32_t)(ASZ + pk * BN + nlc * 64) * 16u);
+      }
+    };
+    // tiles 0 .. NSTAGE-2 in flight, tile 0 landed
+#pragma unroll
+    for (int d = 0; d < NSTAGE - 1; ++d) issue(min(kt0 + d, kt1 - 1), d);
+    wait_vmcnt<PT*(NSTAGE - 2)>();
+    __builtin_amdgcn_s_barrier();
+    int slot = NSTAGE - 1;
+    for (int i = 0; i < nk; ++i) {
+      issue(min(kt0 + i + NSTAGE - 1, kt1 - 1), slot);   // into the slot tile i-1 has just left
+      if (++slot == NSTAGE) slot = 0;
+      wait_vmcnt<PT*(NSTAGE - 2)>();                      // tile i+1 has landed
+      __builtin_amdgcn_s_barrier();
+    }
+    return;
+  }
+
+  // -------------------------------------------------------------------- MFMA waves
+  const int wm = wid / WN, wn = wid % WN, l31 = lane & 31, half = lane >> 5;
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  __builtin_amdgcn_s_barrier();
+  int slot = 0;
+  const long long dbg_c0 = (a.ablate & 64) ? clock64() : 0, dbg_w0 = (a.ablate & 64) ? wall_clock64() : 0;
+  for (int it = 0; it < nk; ++it) {
+    const u32x4* Ab = smem + slot * SSZ;
+    const u32x4* Bb = Ab + ASZ;
+#pragma unroll
+    for (int ks = 0; ks < BK / 16; ++ks) {
+      if (a.ablate & 8) break;
+      const int kc = ks * 2 + half;
+      bf16x8 af[NS][TM], bfr[NS][TN];
+#pragma unroll
+      for (int pp = 0; pp < NS; ++pp) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+          af[pp][i] = __builtin_bit_cast(bf16x8, Ab[(pp * KC + kc) * BM + wm * WTM + i * 32 + l31]);
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          bfr[pp][j] = __builtin_bit_cast(bf16x8, Bb[(pp * KC + kc) * BN + wn * WTN + j * 32 + l31]);
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          f32x16 c = acc[i][j];
+          if constexpr (NS == 3) {
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][i], bfr[1][j], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bfr[2][j], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2][i], bfr[0][j], c, 0, 0, 0);
+          }
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bfr[1][j], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][i], bfr[0][j], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bfr[0][j], c, 0, 0, 0);
+          acc[i][j] = c;
+        }
+    }
+    if (++slot == NSTAGE) slot = 0;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this tile's fragments are in registers
+    __builtin_amdgcn_s_barrier();
+  }
+  if ((a.ablate & 64) && t == 0 && (bid == 0 || bid == 300)) {   // diagnostic: main-loop shader cycles / 100 MHz ticks
+    a.y[(bid ? 2 : 0) + 0] = (float)(clock64() - dbg_c0);
+    a.y[(bid ? 2 : 0) + 1] = (float)(wall_clock64() - dbg_w0);
+    return;
+  }
+
+  float* out = a.y + (size_t)sk * a.slab_stride;
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int nn = n0 + wn * WTN + j * 32 + l31;
+    if (nn >= a.N) continue;
+    const int b2 = nn / HW, hw2 = nn - b2 * HW;
+    const size_t base = (size_t)b2 * a.Co * HW + hw2;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (m < a.Co) {
+          float v = acc[i][j][r];
+          if (a.bias) v += a.bias[m];
+          out[base + (size_t)m * HW] = v;
+        }
+      }
+    }
+  }
+}
+
+// fp32 NCHW -> planes[p][b][c/8][hw] (C % 8 == 0); one thread per chunk, coalesced over hw
+template <int NS>
+__global__ void split_planes_kernel(const float* __restrict__ x, u32x4* __restrict__ planes, int B, int C8, int HW) {
+  const size_t total = (size_t)B * C8 * HW;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t bc = i / HW;
+    const int hw = (int)(i - bc * HW);
+    const float* src = x + bc * 8 * HW + hw;
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = src[(size_t)j * HW];
+    u32x4 pl[NS];
+    split8<NS>(v, pl);
+#pragma unroll
+    for (int p = 0; p < NS; ++p) planes[(size_t)p * total + i] = pl[p];
   }
 }
 
@@ -1252,6 +1476,49 @@ static void launch_fwd_b(const ConvArgsB& a, int bm, int splits, int up2, hipStr
   }
 }
 
+static int bf16p_stages() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("ITCV_BF16P_STAGES");
+    v = (e && e[0] == '2') ? 2 : 3;
+  }
+  return v;
+}
+
+template <int KS, int BM, int BN, int WM, int WN, bool UP2, int NS, int NSTAGE>
+static void launch_fwd_p_cfg(const ConvArgsP& a, int splits, hipStream_t st) {
+  constexpr size_t lds = (size_t)NSTAGE * NS * 4 * (BM + BN) * 16;
+  static_assert(lds <= 160 * 1024, "LDS ring too large");
+  auto kern = conv_fwd_bf16p_kernel<KS, BM, BN, WM, WN, UP2, NS, NSTAGE>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  dim3 grid(cdiv(a.nt, 8) * 8 * a.mt, splits), blk(512);
+  hipLaunchKernelGGL(kern, grid, blk, lds, st, a);
+}
+template <int KS, int NS, int NSTAGE>
+static void launch_fwd_p_st(const ConvArgsP& a, int bm, int splits, int up2, hipStream_t st) {
+  if (bm == 64) {
+    if (up2) launch_fwd_p_cfg<KS, 64, 256, 1, 4, true, NS, NSTAGE>(a, splits, st);
+    else launch_fwd_p_cfg<KS, 64, 256, 1, 4, false, NS, NSTAGE>(a, splits, st);
+  } else {
+    if (up2) launch_fwd_p_cfg<KS, 128, 128, 2, 2, true, NS, NSTAGE>(a, splits, st);
+    else launch_fwd_p_cfg<KS, 128, 128, 2, 2, false, NS, NSTAGE>(a, splits, st);
+  }
+}
+template <int KS, int NS>
+static void launch_fwd_p(const ConvArgsP& a, int bm, int splits, int up2, hipStream_t st) {
+  if constexpr (NS == 2) {
+    if (bf16p_stages() == 3) {
+      launch_fwd_p_st<KS, NS, 3>(a, bm, splits, up2, st);
+      return;
+    }
+  }
+  launch_fwd_p_st<KS, NS, 2>(a, bm, splits, up2, st);
+}
+
 template <int KS, int CB, int NS>
 static void launch_wgrad_b_bm(const WgradArgs& a, int bm, hipStream_t st) {
   dim3 grid(cdiv(a.splits, 8) * 8 * a.tiles);
@@ -1443,6 +1710,79 @@ int itcv_conv2d_fwd_bf16s(const float* x, const void* wp, const float* bias, flo
     hipLaunchKernelGGL(splitk_reduce_fwd, dim3(blocks), dim3(256), 0, st, static_cast<const float*>(ws), bias, y,
                        out_elems, out_elems, p.splits, H * W, Co);
     ITCV_CHECK_LAUNCH("itcv_conv2d_fwd_bf16s(reduce)");
+  }
+  return 0;
+}
+
+size_t itcv_planes_bytes(int B, int C, int HW, int ns) {
+  if (B <= 0 || C <= 0 || HW <= 0 || (C & 7) || ns < 2 || ns > 3) return 0;
+  return (size_t)ns * B * (C / 8) * HW * 16;
+}
+
+int itcv_split_planes(const float* x, void* planes, int B, int C, int HW, int ns, void* stream) {
+  ITCV_REQUIRE(x && planes && B > 0 && C > 0 && HW > 0 && (C & 7) == 0 && (ns == 2 || ns == 3), "itcv_split_planes");
+  const size_t total = (size_t)B * (C / 8) * HW;
+  const int blocks = (int)(cdivz(total, 256) < 8192 ? cdivz(total, 256) : 8192);
+  if (ns == 2)
+    hipLaunchKernelGGL(split_planes_kernel<2>, dim3(blocks), dim3(256), 0, S(stream), x, static_cast<u32x4*>(planes), B,
+                       C / 8, HW);
+  else
+    hipLaunchKernelGGL(split_planes_kernel<3>, dim3(blocks), dim3(256), 0, S(stream), x, static_cast<u32x4*>(planes), B,
+                       C / 8, HW);
+  ITCV_CHECK_LAUNCH("itcv_split_planes");
+  return 0;
+}
+
+// Same contract as itcv_conv2d_fwd_bf16s, with the input given as pre-split planes
+// ([ns][B][Ci/8][Hs][Ws] 16-byte chunks; Hs,Ws = H/2,W/2 when up2).  Workspace: itcv_conv2d_fwd_bf16s_workspace.
+int itcv_conv2d_fwd_bf16p(const void* xplanes, const void* wp, const float* bias, float* y, int B, int Ci, int H,
+                          int W, int Co, int KS, int up2, int ns, void* ws, size_t ws_bytes, void* stream) {
+  if (int e = check_dims("itcv_conv2d_fwd_bf16p", B, Ci, H, W, Co, KS)) return e;
+  ITCV_REQUIRE(xplanes && wp && y && (ns == 2 || ns == 3), "itcv_conv2d_fwd_bf16p");
+  if (!itcv_conv2d_bf16s_supported(Ci, Co, KS))
+    return fail("%s: shape not supported by the split-bf16 kernel (Ci %% 32, Co > 32, KS 1/3)", "itcv_conv2d_fwd_bf16p");
+  if (up2) ITCV_REQUIRE(H % 2 == 0 && W % 2 == 0, "itcv_conv2d_fwd_bf16p(up2)");
+  const FwdPlanB p = plan_fwd_b(B, Ci, H, W, Co, KS);
+  const size_t out_elems = (size_t)B * Co * H * W;
+  if (p.splits > 1 && (!ws || ws_bytes < (size_t)p.splits * out_elems * sizeof(float)))
+    return fail("%s: workspace too small (need %lld bytes)", "itcv_conv2d_fwd_bf16p",
+                (long long)((size_t)p.splits * out_elems * sizeof(float)));
+  ConvArgsP a;
+  a.xp = static_cast<const u32x4*>(xplanes);
+  a.wp = static_cast<const u32x4*>(wp);
+  a.bias = p.splits > 1 ? nullptr : bias;
+  a.y = p.splits > 1 ? static_cast<float*>(ws) : y;
+  a.B = B, a.Ci = Ci, a.H = H, a.W = W, a.Co = Co;
+  a.Mp = p.mt * p.bm;
+  a.N = B * H * W;
+  a.mt = p.mt, a.nt = p.nt, a.ktiles = p.ktiles, a.ktiles_per_split = p.kps;
+  a.slab_stride = p.splits > 1 ? out_elems : 0;
+  a.plane_stride = (size_t)B * (Ci / 8) * (up2 ? (H / 2) * (W / 2) : H * W);
+  {
+    static int abl = -1;
+    if (abl < 0) {
+      const char* e = getenv("ITCV_ABLATE");
+      abl = e ? atoi(e) : 0;
+    }
+    a.ablate = abl;
+  }
+  hipStream_t st = S(stream);
+  {
+    ProfScope prof(st, 6, KS, p.bm, up2 ? 1 : 0, ns, 2.0 * B * H * W * (double)Co * Ci * KS * KS);
+    if (KS == 1) {
+      if (ns == 2) launch_fwd_p<1, 2>(a, p.bm, p.splits, up2, st);
+      else launch_fwd_p<1, 3>(a, p.bm, p.splits, up2, st);
+    } else {
+      if (ns == 2) launch_fwd_p<3, 2>(a, p.bm, p.splits, up2, st);
+      else launch_fwd_p<3, 3>(a, p.bm, p.splits, up2, st);
+    }
+  }
+  ITCV_CHECK_LAUNCH("itcv_conv2d_fwd_bf16p");
+  if (p.splits > 1) {
+    const int blocks = (int)(cdivz(out_elems, 256) < 2048 ? cdivz(out_elems, 256) : 2048);
+    hipLaunchKernelGGL(splitk_reduce_fwd, dim3(blocks), dim3(256), 0, st, static_cast<const float*>(ws), bias, y,
+                       out_elems, out_elems, p.splits, H * W, Co);
+    ITCV_CHECK_LAUNCH("itcv_conv2d_fwd_bf16p(reduce)");
   }
   return 0;
 }

@@ -71,6 +71,9 @@ _CONV_MATH = [_os.environ.get("ITCV_CONV_MATH", "fp32")]
 assert _CONV_MATH[0] in _NS, "ITCV_CONV_MATH must be one of fp32 / bf16x3 / bf16x6"
 
 
+_PLANES = [_os.environ.get("ITCV_PLANES", "1") != "0"]   # split-bf16 convs take pre-split operands (LDS-DMA kernels)
+
+
 def set_conv_math(mode):
     """Arithmetic of the conv/linear forward and data-gradient GEMMs:
     'fp32'   exact fp32 MFMA (v_mfma_f32_32x32x2_f32) -- the parity path and the default;
@@ -142,6 +145,10 @@ def conv_apply(x, weight, w4, for_dgrad, bias, B, Ci, H, W, Co, KS, up2):
              stream())
         return y
     ns = _NS[_CONV_MATH[0]]
+    if ns and _PLANES[0] and lib.itcv_conv2d_bf16s_supported(Ci, Co, KS):
+        # pre-split the input once (HBM-bound pass), then the LDS-DMA kernel: no gather / conversion in the GEMM
+        xs = x if x.dim() == 4 else x.view(B, Ci, H // 2 if up2 else H, W // 2 if up2 else W)
+        return conv_apply_planes(split_planes(xs, ns), weight, w4, for_dgrad, bias, B, Ci, H, W, Co, KS, up2, ns)
     if ns and lib.itcv_conv2d_bf16s_supported(Ci, Co, KS):
         wp = packed_weight(weight, w4, for_dgrad, ns)
         y = torch.empty((B, Co, H, W), dtype=F32, device=x.device)
@@ -152,6 +159,29 @@ def conv_apply(x, weight, w4, for_dgrad, bias, B, Ci, H, W, Co, KS, up2):
              stream())
         return y
     return conv_fwd_raw(x, packed_weight(weight, w4, for_dgrad), bias, B, Ci, H, W, Co, KS, up2)
+
+
+def split_planes(x, ns):
+    """fp32 [B,C,H,W] -> pre-split bf16 planes [ns][B][C/8][H][W] x 16 B (see include/itcv_hip.h)."""
+    B, C, H, W = x.shape
+    nbytes = lib.itcv_planes_bytes(B, C, H * W, ns)
+    if not nbytes:
+        raise abi.HipExtensionError(f"split_planes: unsupported shape {tuple(x.shape)} / ns={ns}")
+    xp = torch.empty(nbytes // 4, dtype=torch.int32, device=x.device)
+    call("itcv_split_planes", ptr(x), ptr(xp), B, C, H * W, ns, stream())
+    return xp
+
+
+def conv_apply_planes(xp, weight, w4, for_dgrad, bias, B, Ci, H, W, Co, KS, up2, ns):
+    """conv_apply with the input given as pre-split planes (LDS-DMA kernel, no gather)."""
+    wp = packed_weight(weight, w4, for_dgrad, ns)
+    y = torch.empty((B, Co, H, W), dtype=F32, device=xp.device)
+    nws = lib.itcv_conv2d_fwd_bf16s_workspace(B, Ci, H, W, Co, KS)
+    ws = _ws(nws, xp.device) if nws else None
+
+    call("itcv_conv2d_fwd_bf16p", ptr(xp), ptr(wp), ptr(bias), ptr(y), B, Ci, H, W, Co, KS, int(up2), ns, ptr(ws), nws,
+         stream())
+    return y
 
 
 def pack_weight(w4, for_dgrad):
@@ -166,7 +196,7 @@ class LaunchProfile:
     """Per-launch timing of the GEMM-class kernels, recorded INSIDE libitcv_hip.so: a HIP event pair on
     the launch stream around the main kernel of every conv call (bench.py's roofline leg)."""
     KINDS = {0: "conv_fwd_kernel", 1: "conv_fwd_bf16s_kernel", 2: "conv_wgrad_kernel", 3: "conv_wgrad_bf16s_kernel",
-             4: "conv_small_cout_kernel", 5: "conv_small_cin_kernel"}
+             4: "conv_small_cout_kernel", 5: "conv_small_cin_kernel", 6: "conv_fwd_bf16p_kernel"}
 
     @classmethod
     def begin(cls):
@@ -185,7 +215,7 @@ class LaunchProfile:
             kind, ks, bm, up2, ns = c & 15, (c >> 4) & 15, (c >> 8) & 255, (c >> 16) & 1, (c >> 20) & 15
             if kind in (0, 2):
                 label = f"{cls.KINDS[kind]}<KS={ks},BM={bm},up2={up2}>"
-            elif kind in (1, 3):
+            elif kind in (1, 3, 6):
                 label = f"{cls.KINDS[kind]}<KS={ks},BM={bm},up2={up2},NS={ns}>"
             else:
                 label = f"{cls.KINDS[kind]}<KS={ks},C={bm}>"
