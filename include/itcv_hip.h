@@ -35,7 +35,8 @@ const char* itcv_last_error(void);
  * _end every conv entry point records a HIP event pair on its launch stream around its MAIN kernel
  * (not the split-K reduce).  _end waits for the events and returns the record count; record i is
  * (code = kind | KS<<4 | BM<<8 | up2<<16 | NS<<20 with kind 0 fwd fp32, 1 fwd split-bf16, 2 wgrad fp32,
- * 3 wgrad split-bf16, 4 small-Cout direct, 5 small-Cin direct; algorithmic FLOP; elapsed ms). */
+ * 3 wgrad split-bf16, 4 small-Cout direct, 5 small-Cin direct, 6 fwd on planes, 7 wgrad on planes;
+ * algorithmic FLOP; elapsed ms). */
 int itcv_profile_begin(void);
 int itcv_profile_end(void);
 int itcv_profile_get(int i, int* code, double* flop, float* ms);
@@ -83,6 +84,14 @@ size_t itcv_planes_bytes(int B, int C, int HW, int ns);
 int itcv_split_planes(const float* x, void* planes, int B, int C, int HW, int ns, void* stream);
 int itcv_conv2d_fwd_bf16p(const void* xplanes, const void* wp, const float* bias, float* y, int B, int Ci, int H,
                           int W, int Co, int KS, int up2, int ns, void* ws, size_t ws_bytes, void* stream);
+/* Weight gradient from the same planes (x: [2][B][Ci/8][Hs][Ws], dy: [2][B][Co/8][H][W]); the pixel
+ * reduction runs through the gfx950 transposing LDS read, so no pixel-major copy is needed.  bf16x3
+ * only; KS = 3, W a power of two in 4..64, H a power of two, B*H*W % 64 == 0 (see _supported).  Replaces
+ * the ATen conv weight-gradient (backward of models.py:28-47).  Deterministic split-K (fp32 slabs). */
+int itcv_conv2d_wgrad_bf16p_supported(int B, int Ci, int H, int W, int Co, int KS);
+size_t itcv_conv2d_wgrad_bf16p_workspace(int B, int Ci, int H, int W, int Co, int KS);
+int itcv_conv2d_wgrad_bf16p(const void* xplanes, const void* dyplanes, float* dw, int B, int Ci, int H, int W,
+                            int Co, int KS, int up2, int accumulate, void* ws, size_t ws_bytes, void* stream);
 /* Direct (vector-ALU, exact fp32) convolution for layers with at most 4 output channels -- the 5x5
  * predict conv 64->3 (models.py:290) and the data-gradient of the 5x5 stem (models.py:213), where a
  * 32-row MFMA tile would be >90 % padding.  for_dgrad = 0: w is [Co][C][KS][KS]; for_dgrad = 1: w is the

@@ -263,7 +263,7 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void lds_dma16(const void* gptr, uint32_t lds_base) {
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off"
                :
-               : "s"(lds_base), "v"(gptr)
+               : "s"(__builtin_amdgcn_readfirstlane(lds_base)), "v"(gptr)
                : "memory", "m0");
 }
 __device__ __forceinline__ uint32_t lds_addr(const void* p) {
@@ -1258,6 +1258,197 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_wgrad_bf16s_kernel(WgradArgs
   }
 }
 
+// ---------------------------------------------------------- weight gradient on pre-split planes
+// dW[co][ci][dh][dw] = sum over pixels of dY[co][px] * X[ci][px + (dh, dw)], with BOTH operands given as the
+// channel-blocked planes the forward / data-gradient kernels use (chunk = 8 channels of one pixel).  The
+// reduction index is the pixel, so in LDS the operands are "K-major"; the MFMA fragments (8 consecutive
+// pixels of one channel per lane) come out of ds_read_b64_tr_b16, the gfx950 transposing LDS read -- no
+// second copy of the activations in a pixel-major layout is ever made.
+//   block  = 128 output channels x 64 input channels x the 3 taps of one filter row (dh), one K slice
+//   step   = 64 consecutive pixels; X arrives once per step as a halo'd band (NR rows x (W+2) columns, the
+//            rows already shifted by dh): the 3 taps read it at column offsets -1/0/+1
+//   waves  = 8 MFMA waves (4 x 2, a 32x32 tile x 3 taps each) + 4 loader waves (LDS-DMA, two stages)
+// Padding is a zero chunk at DMA time; the MFMA loop has no bounds logic.  Partial sums go to fp32 slabs
+// [split][tap][co][ci], reduced in a fixed order by wgrad_p_reduce (bitwise reproducible).
+struct WgradArgsP {
+  const u32x4* xp;
+  const u32x4* dyp;
+  float* slab;
+  int B, Ci, H, W, Co;
+  int tiles_m, tiles_n;
+  int steps, steps_per_split, splits;
+  int h_shift;
+  size_t xplane, dyplane;   // chunks per plane
+};
+
+__device__ __forceinline__ void tr_read8(bf16x8& dst, uint32_t addr0, uint32_t addr1) {
+  typedef short s16x4 __attribute__((ext_vector_type(4)));
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(size_t)addr0);
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(size_t)addr1);
+  typedef short s16x8 __attribute__((ext_vector_type(8)));
+  const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  dst = __builtin_bit_cast(bf16x8, v);
+}
+
+template <int LOG2W, bool UP2>
+__global__ __launch_bounds__(768) void conv_wgrad_bf16p_kernel(WgradArgsP a) {
+  constexpr int W = 1 << LOG2W, NR = 64 >> LOG2W, WP = W + 2, NP = NR * WP;   // band: NR rows x (W+2) columns
+  constexpr int PXA = 68, PXB = ((NP + 11) / 16) * 16 + 4;                     // row strides = 4 (mod 16) chunks: conflict-free tr reads
+  static_assert(PXB >= NP && PXB % 16 == 4, "band stride");
+  constexpr int ASZ = 2 * 16 * PXA, BSZ = 2 * 8 * PXB, SSZ = ASZ + BSZ;        // chunks per stage
+  extern __shared__ u32x4 smem[];
+
+  const int t = threadIdx.x, lane = t & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(t >> 6);
+  int bid = blockIdx.x;
+  const int split = bid % a.splits;
+  bid /= a.splits;
+  const int dhi = bid % 3;
+  bid /= 3;
+  const int tn = bid % a.tiles_n, tm = bid / a.tiles_n;
+  const int co0 = tm * 128, ci0 = tn * 64;
+  const int s0 = split * a.steps_per_split, s1 = min(a.steps, s0 + a.steps_per_split);
+  const int H = a.H, HW = H * W;
+  const uint32_t smem_base = lds_addr(smem);
+
+  if (wid >= 8) {
+    // ------------------------------------------------------------------ loaders
+    if (s0 >= s1) return;
+    const int lw = wid - 8;
+    const int Hs = UP2 ? H / 2 : H, Ws = UP2 ? W / 2 : W, HWs = Hs * Ws;
+    const int Co8 = a.Co >> 3, Ci8 = a.Ci >> 3, dh = dhi - 1;
+    const u32x4* zero = &g_zero_chunk;
+    // this wave's band pixel (same for all of its X pieces): half = lw & 1
+    const int hp = (lw & 1) * 64 + lane;
+    const bool hp_active = hp < NP;
+    const int R = hp / WP, w = hp - R * WP - 1;
+    const bool w_ok = (unsigned)w < (unsigned)W;
+
+    auto issue = [&](int st, int stage) {
+      const uint32_t sbase = smem_base + (uint32_t)(stage * SSZ) * 16u;
+      // dY: 64 consecutive pixels of the step, 16 channel chunks x 2 planes = 32 pieces; this wave: q = 4j + lw
+      {
+        const int g = st * 64 + lane, b = g / HW, pix = g - b * HW;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int qq = j * 4 + lw, pl = qq >> 4, c8 = qq & 15;
+          const int gc8 = (co0 >> 3) + c8;
+          const u32x4* src = a.dyp + ((size_t)pl * a.dyplane + ((size_t)b * Co8 + gc8) * HW + pix);
+          lds_dma16(gc8 < Co8 ? src : zero, sbase + (uint32_t)((pl * 16 + c8) * PXA) * 16u);
+        }
+      }
+      // X band: rows st*NR .. st*NR+NR-1 of the (batch x height) row index, shifted by dh; 2 pieces per (plane, chunk row)
+      {
+        const int gr = st * NR + R, b = gr >> a.h_shift, h = gr & (H - 1), hh = h + dh;
+        const bool valid = w_ok && (unsigned)hh < (unsigned)H;
+        const int spix = UP2 ? (hh >> 1) * Ws + (w >> 1) : hh * W + w;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int qq = (j * 4 + lw) >> 1, pl = qq >> 3, c8 = qq & 7;
+          const int gc8 = (ci0 >> 3) + c8;
+          const u32x4* src = a.xp + ((size_t)pl * a.xplane + ((size_t)b * Ci8 + gc8) * HWs + spix);
+          if (hp_active)
+            lds_dma16((valid && gc8 < Ci8) ? src : zero,
+                      sbase + (uint32_t)(ASZ + (pl * 8 + c8) * PXB + (lw & 1) * 64) * 16u);
+        }
+      }
+    };
+    issue(s0, 0);
+    wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    int stage = 1;
+    for (int st = s0; st < s1; ++st) {
+      if (st + 1 < s1) issue(st + 1, stage);
+      stage ^= 1;
+      wait_vmcnt<0>();
+      __builtin_amdgcn_s_barrier();
+    }
+    return;
+  }
+
+  // -------------------------------------------------------------------- MFMA waves
+  const int wm = wid >> 1, wn = wid & 1;
+  const int G = lane >> 4, i16 = lane & 15, q = i16 >> 2, pp = i16 & 3, half = G >> 1, rb = G & 1;
+  const int l31 = lane & 31;
+  f32x16 acc[3];
+#pragma unroll
+  for (int tp = 0; tp < 3; ++tp)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[tp][r] = 0.f;
+  if (s0 < s1) {
+    // byte offsets inside a stage of this lane's transposed reads (plane 0, k-step 0, first half)
+    const uint32_t aoff = (uint32_t)(((4 * wm + 2 * rb + (pp >> 1)) * PXA + half * 8 + q) * 16 + (pp & 1) * 8);
+    const uint32_t boff = (uint32_t)((ASZ + (4 * wn + 2 * rb + (pp >> 1)) * PXB) * 16 + (pp & 1) * 8);
+    // band index of pixel k = kk*16 + half*8 + s*4 + q, for the 8 (kk, s) pairs, centre tap
+    uint32_t hidx16[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int k = (u >> 1) * 16 + half * 8 + (u & 1) * 4 + q;
+      hidx16[u] = (uint32_t)(((k >> LOG2W) * WP + (k & (W - 1)) + 1) * 16);
+    }
+    __builtin_amdgcn_s_barrier();
+    int stage = 0;
+    for (int st = s0; st < s1; ++st) {
+      const uint32_t sb = smem_base + (uint32_t)(stage * SSZ) * 16u;
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        bf16x8 af[2];
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) {
+          const uint32_t ad = sb + aoff + (uint32_t)(pl * 16 * PXA * 16 + kk * 256);
+          tr_read8(af[pl], ad, ad + 64);
+        }
+#pragma unroll
+        for (int tp = 0; tp < 3; ++tp) {
+          bf16x8 bfr[2];
+#pragma unroll
+          for (int pl = 0; pl < 2; ++pl) {
+            const uint32_t bd = sb + boff + (uint32_t)(pl * 8 * PXB * 16 + (tp - 1) * 16);
+            tr_read8(bfr[pl], bd + hidx16[kk * 2], bd + hidx16[kk * 2 + 1]);
+          }
+          f32x16 c = acc[tp];
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bfr[1], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], bfr[0], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bfr[0], c, 0, 0, 0);
+          acc[tp] = c;
+        }
+      }
+      stage ^= 1;
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
+  }
+  // slab[split][tap][co][ci]
+  const int ci = ci0 + 32 * wn + l31;
+  if (ci < a.Ci) {
+#pragma unroll
+    for (int tp = 0; tp < 3; ++tp) {
+      float* out = a.slab + ((size_t)(split * 9 + dhi * 3 + tp) * a.Co) * a.Ci + ci;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = co0 + 32 * wm + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (co < a.Co) out[(size_t)co * a.Ci] = acc[tp][r];
+      }
+    }
+  }
+}
+
+// dw[co][ci][tap] (+)= sum_s slab[s][tap][co][ci]   (one thread per (co, ci): coalesced slab reads, fixed order)
+__global__ void wgrad_p_reduce(const float* __restrict__ slab, float* __restrict__ dw, int CoCi, int splits,
+                               int accumulate) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < CoCi; i += gridDim.x * blockDim.x) {
+    float s[9];
+#pragma unroll
+    for (int tp = 0; tp < 9; ++tp) s[tp] = accumulate ? dw[(size_t)i * 9 + tp] : 0.f;
+    for (int k = 0; k < splits; ++k) {
+#pragma unroll
+      for (int tp = 0; tp < 9; ++tp) s[tp] += slab[((size_t)k * 9 + tp) * CoCi + i];
+    }
+#pragma unroll
+    for (int tp = 0; tp < 9; ++tp) dw[(size_t)i * 9 + tp] = s[tp];
+  }
+}
+
 // dw[co][ci][tap] (+)= sum_s slab[s][co][column(tap, ci)]
 __global__ void splitk_reduce_wgrad(const float* __restrict__ slab, float* __restrict__ dw, int Co, int Ci, int KK,
                                     int Cip, int cb, int Np, size_t slab_stride, int splits, int accumulate) {
@@ -1517,6 +1708,45 @@ static void launch_fwd_p(const ConvArgsP& a, int bm, int splits, int up2, hipStr
     }
   }
   launch_fwd_p_st<KS, NS, 2>(a, bm, splits, up2, st);
+}
+
+struct WgPlanP {
+  int tiles_m, tiles_n, steps, splits, sps;
+};
+static WgPlanP plan_wgrad_p(int B, int Ci, int H, int W, int Co) {
+  WgPlanP p;
+  p.tiles_m = cdiv(Co, 128), p.tiles_n = cdiv(Ci, 64);
+  p.steps = (int)(((long long)B * H * W) / 64);
+  const int T = p.tiles_m * p.tiles_n * 3;
+  int splits = 256 / T;                       // one 768-thread block per CU
+  if (splits > p.steps / 2) splits = p.steps / 2;
+  if (splits < 1) splits = 1;
+  p.sps = cdiv(p.steps, splits);
+  p.splits = cdiv(p.steps, p.sps);
+  return p;
+}
+
+template <int LOG2W>
+static void launch_wgrad_p(const WgradArgsP& a, int up2, int blocks, hipStream_t st) {
+  constexpr int W = 1 << LOG2W, NP = (64 >> LOG2W) * (W + 2), PXB = ((NP + 11) / 16) * 16 + 4;
+  constexpr size_t lds = (size_t)2 * (2 * 16 * 68 + 2 * 8 * PXB) * 16;
+  static_assert(lds <= 160 * 1024, "LDS");
+  static bool attr_set[2] = {false, false};
+  if (up2) {
+    auto kern = conv_wgrad_bf16p_kernel<LOG2W, true>;
+    if (!attr_set[1]) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      attr_set[1] = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(768), lds, st, a);
+  } else {
+    auto kern = conv_wgrad_bf16p_kernel<LOG2W, false>;
+    if (!attr_set[0]) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      attr_set[0] = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(768), lds, st, a);
+  }
 }
 
 template <int KS, int CB, int NS>
@@ -1883,6 +2113,63 @@ int itcv_conv2d_wgrad_bf16s(const float* x, const float* dy, float* dw, int B, i
   hipLaunchKernelGGL(splitk_reduce_wgrad, dim3(blocks), dim3(256), 0, st, static_cast<const float*>(ws), dw, Co, Ci,
                      KS * KS, p.cip, p.cb, a.Np, slab, p.splits, accumulate);
   ITCV_CHECK_LAUNCH("itcv_conv2d_wgrad_bf16s(reduce)");
+  return 0;
+}
+
+// ---- weight gradient on pre-split planes ------------------------------------------------------
+int itcv_conv2d_wgrad_bf16p_supported(int B, int Ci, int H, int W, int Co, int KS) {
+  if (KS != 3 || B <= 0 || Ci < 8 || Co < 8 || (Ci & 7) || (Co & 7)) return 0;
+  if (log2_exact(W) < 2 || W > 64 || log2_exact(H) < 0) return 0;
+  const long long px = (long long)B * H * W;
+  if (px % 64) return 0;
+  if (H * W < 64 && 64 % (H * W)) return 0;
+  return 1;
+}
+
+size_t itcv_conv2d_wgrad_bf16p_workspace(int B, int Ci, int H, int W, int Co, int KS) {
+  if (!itcv_conv2d_wgrad_bf16p_supported(B, Ci, H, W, Co, KS)) return 0;
+  const WgPlanP p = plan_wgrad_p(B, Ci, H, W, Co);
+  return (size_t)p.splits * 9 * Co * Ci * sizeof(float);
+}
+
+// dw[Co][Ci][3][3] (+)= conv weight gradient from the pre-split planes of x ([2][B][Ci/8][Hs][Ws]; Hs,Ws =
+// H/2,W/2 with up2) and dy ([2][B][Co/8][H][W]); bf16x3 arithmetic (two planes).
+int itcv_conv2d_wgrad_bf16p(const void* xplanes, const void* dyplanes, float* dw, int B, int Ci, int H, int W, int Co,
+                            int KS, int up2, int accumulate, void* ws, size_t ws_bytes, void* stream) {
+  if (int e = check_dims("itcv_conv2d_wgrad_bf16p", B, Ci, H, W, Co, KS)) return e;
+  ITCV_REQUIRE(xplanes && dyplanes && dw, "itcv_conv2d_wgrad_bf16p");
+  if (!itcv_conv2d_wgrad_bf16p_supported(B, Ci, H, W, Co, KS))
+    return fail("%s: shape not supported (KS 3, W a power of two in 4..64, H a power of two, C %% 8)", "itcv_conv2d_wgrad_bf16p");
+  if (up2) ITCV_REQUIRE(H % 2 == 0 && W % 2 == 0, "itcv_conv2d_wgrad_bf16p(up2)");
+  const WgPlanP p = plan_wgrad_p(B, Ci, H, W, Co);
+  const size_t need = (size_t)p.splits * 9 * Co * Ci * sizeof(float);
+  if (!ws || ws_bytes < need) return fail("%s: workspace too small (need %lld bytes)", "itcv_conv2d_wgrad_bf16p", (long long)need);
+  WgradArgsP a;
+  a.xp = static_cast<const u32x4*>(xplanes), a.dyp = static_cast<const u32x4*>(dyplanes);
+  a.slab = static_cast<float*>(ws);
+  a.B = B, a.Ci = Ci, a.H = H, a.W = W, a.Co = Co;
+  a.tiles_m = p.tiles_m, a.tiles_n = p.tiles_n;
+  a.steps = p.steps, a.steps_per_split = p.sps, a.splits = p.splits;
+  a.h_shift = log2_exact(H);
+  a.xplane = (size_t)B * (Ci / 8) * (up2 ? (H / 2) * (W / 2) : H * W);
+  a.dyplane = (size_t)B * (Co / 8) * H * W;
+  hipStream_t st = S(stream);
+  const int blocks = p.tiles_m * p.tiles_n * 3 * p.splits;
+  {
+    ProfScope prof(st, 7, KS, 128, up2 ? 1 : 0, 2, 2.0 * B * H * W * (double)Co * Ci * KS * KS);
+    switch (log2_exact(W)) {
+      case 2: launch_wgrad_p<2>(a, up2, blocks, st); break;
+      case 3: launch_wgrad_p<3>(a, up2, blocks, st); break;
+      case 4: launch_wgrad_p<4>(a, up2, blocks, st); break;
+      case 5: launch_wgrad_p<5>(a, up2, blocks, st); break;
+      default: launch_wgrad_p<6>(a, up2, blocks, st); break;
+    }
+  }
+  ITCV_CHECK_LAUNCH("itcv_conv2d_wgrad_bf16p");
+  const int coci = Co * Ci;
+  hipLaunchKernelGGL(wgrad_p_reduce, dim3(cdiv(coci, 256) < 2048 ? cdiv(coci, 256) : 2048), dim3(256), 0, st,
+                     static_cast<const float*>(ws), dw, coci, p.splits, accumulate);
+  ITCV_CHECK_LAUNCH("itcv_conv2d_wgrad_bf16p(reduce)");
   return 0;
 }
 

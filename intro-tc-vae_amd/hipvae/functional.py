@@ -145,10 +145,6 @@ def conv_apply(x, weight, w4, for_dgrad, bias, B, Ci, H, W, Co, KS, up2):
              stream())
         return y
     ns = _NS[_CONV_MATH[0]]
-    if ns and _PLANES[0] and lib.itcv_conv2d_bf16s_supported(Ci, Co, KS):
-        # pre-split the input once (HBM-bound pass), then the LDS-DMA kernel: no gather / conversion in the GEMM
-        xs = x if x.dim() == 4 else x.view(B, Ci, H // 2 if up2 else H, W // 2 if up2 else W)
-        return conv_apply_planes(split_planes(xs, ns), weight, w4, for_dgrad, bias, B, Ci, H, W, Co, KS, up2, ns)
     if ns and lib.itcv_conv2d_bf16s_supported(Ci, Co, KS):
         wp = packed_weight(weight, w4, for_dgrad, ns)
         y = torch.empty((B, Co, H, W), dtype=F32, device=x.device)
@@ -184,6 +180,17 @@ def conv_apply_planes(xp, weight, w4, for_dgrad, bias, B, Ci, H, W, Co, KS, up2,
     return y
 
 
+def conv_wgrad_planes(xp, dyp, B, Ci, H, W, Co, KS, up2, out=None, accumulate=False):
+    """Weight gradient from the pre-split planes of x and dy (bf16x3; transposing-LDS-read kernel)."""
+    dw = out if out is not None else torch.empty((Co, Ci, KS, KS), dtype=F32, device=xp.device)
+    nws = lib.itcv_conv2d_wgrad_bf16p_workspace(B, Ci, H, W, Co, KS)
+    ws = _ws(nws, xp.device)
+
+    call("itcv_conv2d_wgrad_bf16p", ptr(xp), ptr(dyp), ptr(dw), B, Ci, H, W, Co, KS, int(up2), int(accumulate), ptr(ws),
+         nws, stream())
+    return dw
+
+
 def pack_weight(w4, for_dgrad):
     """w4 [Co,Ci,KS,KS] -> packed K-major operand (see include/itcv_hip.h)."""
     co, ci, ks = w4.shape[0], w4.shape[1], w4.shape[2]
@@ -196,7 +203,8 @@ class LaunchProfile:
     """Per-launch timing of the GEMM-class kernels, recorded INSIDE libitcv_hip.so: a HIP event pair on
     the launch stream around the main kernel of every conv call (bench.py's roofline leg)."""
     KINDS = {0: "conv_fwd_kernel", 1: "conv_fwd_bf16s_kernel", 2: "conv_wgrad_kernel", 3: "conv_wgrad_bf16s_kernel",
-             4: "conv_small_cout_kernel", 5: "conv_small_cin_kernel", 6: "conv_fwd_bf16p_kernel"}
+             4: "conv_small_cout_kernel", 5: "conv_small_cin_kernel", 6: "conv_fwd_bf16p_kernel",
+             7: "conv_wgrad_bf16p_kernel"}
 
     @classmethod
     def begin(cls):
@@ -215,7 +223,7 @@ class LaunchProfile:
             kind, ks, bm, up2, ns = c & 15, (c >> 4) & 15, (c >> 8) & 255, (c >> 16) & 1, (c >> 20) & 15
             if kind in (0, 2):
                 label = f"{cls.KINDS[kind]}<KS={ks},BM={bm},up2={up2}>"
-            elif kind in (1, 3, 6):
+            elif kind in (1, 3, 6, 7):
                 label = f"{cls.KINDS[kind]}<KS={ks},BM={bm},up2={up2},NS={ns}>"
             else:
                 label = f"{cls.KINDS[kind]}<KS={ks},C={bm}>"
@@ -262,9 +270,26 @@ def bias_grad_raw(dy, B, C, HW, target=None):
     return None if target is not None else db
 
 
+def _planes_ns(Ci, Co, KS, up2):
+    """Number of bf16 planes when a forward-type conv GEMM (Ci -> Co) runs on pre-split operands, else 0."""
+    ns = _NS[_CONV_MATH[0]]
+    if not ns or not _PLANES[0]:
+        return 0
+    if not up2 and (lib.itcv_conv2d_small_cout_supported(Co, KS) or lib.itcv_conv2d_small_cin_supported(Ci, KS)):
+        return 0
+    return ns if lib.itcv_conv2d_bf16s_supported(Ci, Co, KS) else 0
+
+
+def _wgrad_planes_ok(B, Ci, H, W, Co, KS):
+    return bool(_NS[_CONV_MATH[0]] == 2 and _PLANES[0] and lib.itcv_conv2d_wgrad_bf16p_supported(B, Ci, H, W, Co, KS))
+
+
 class Conv2dFn(Function):
     """nn.Conv2d(stride 1, padding KS//2) forward/backward; ``up2`` reads the input through a
-    virtual nearest x2 upsampling (models.py:284-286 fused into the consumer conv)."""
+    virtual nearest x2 upsampling (models.py:284-286 fused into the consumer conv).
+
+    In the split-bf16 modes the operands travel as pre-split planes: x is split once in forward (and
+    kept for the weight gradient), dy once in backward (shared by data- and weight-gradient)."""
 
     @staticmethod
     def forward(ctx, x, weight, bias, up2):
@@ -272,30 +297,57 @@ class Conv2dFn(Function):
         B, Ci, Hs, Ws = x.shape
         Co, KS = weight.shape[0], weight.shape[2]
         H, W = (Hs * 2, Ws * 2) if up2 else (Hs, Ws)
-        y = conv_apply(x, weight, weight, 0, None if bias is None else _f32c(bias), B, Ci, H, W, Co, KS, up2)
-        ctx.save_for_backward(x, weight, bias)
-        ctx.cfg = (B, Ci, H, W, Co, KS, up2, bias is not None)
+        b = None if bias is None else _f32c(bias)
+        ns = _planes_ns(Ci, Co, KS, up2)
+        xp = None
+        if ns:
+            xp = split_planes(x, ns)
+            y = conv_apply_planes(xp, weight, weight, 0, b, B, Ci, H, W, Co, KS, up2, ns)
+        else:
+            y = conv_apply(x, weight, weight, 0, b, B, Ci, H, W, Co, KS, up2)
+        wg_planes = _wgrad_planes_ok(B, Ci, H, W, Co, KS)
+        keep_xp = xp if (wg_planes and ns == 2) else None
+        ctx.save_for_backward(None if keep_xp is not None else x, weight, bias, keep_xp)
+        ctx.cfg = (B, Ci, H, W, Co, KS, up2, bias is not None, (Hs, Ws))
         return y
 
     @staticmethod
     @once_differentiable
     def backward(ctx, dy):
-        x, weight, bias = ctx.saved_tensors
-        B, Ci, H, W, Co, KS, up2, has_bias = ctx.cfg
+        x, weight, bias, xp = ctx.saved_tensors
+        B, Ci, H, W, Co, KS, up2, has_bias, (Hs, Ws) = ctx.cfg
         dy = _f32c(dy)
         dx = dw = db = None
+        ns_d = _planes_ns(Co, Ci, KS, False) if ctx.needs_input_grad[0] else 0
+        wg_planes = ctx.needs_input_grad[1] and _wgrad_planes_ok(B, Ci, H, W, Co, KS)
+        dyp = None
+        if ns_d or wg_planes:
+            dyp = split_planes(dy, ns_d if ns_d else 2)
         if ctx.needs_input_grad[0]:
-            dx = conv_apply(dy, weight, weight, 1, None, B, Co, H, W, Ci, KS, False)
+            if ns_d:
+                dx = conv_apply_planes(dyp, weight, weight, 1, None, B, Co, H, W, Ci, KS, False, ns_d)
+            else:
+                dx = conv_apply(dy, weight, weight, 1, None, B, Co, H, W, Ci, KS, False)
             if up2:
                 lo = torch.empty((B, Ci, H // 2, W // 2), dtype=F32, device=dy.device)
                 call("itcv_upsample2_bwd", ptr(dx), ptr(lo), B * Ci, H // 2, W // 2, stream())
                 dx = lo
         if ctx.needs_input_grad[1]:
             tgt = _grad_target(weight)
-            if tgt is not None:
-                conv_wgrad_raw(x, dy, B, Ci, H, W, Co, KS, up2, out=tgt, accumulate=True)
+            if wg_planes and (ns_d in (0, 2)):
+                if xp is None:
+                    xp = split_planes(x, 2)
+                if tgt is not None:
+                    conv_wgrad_planes(xp, dyp, B, Ci, H, W, Co, KS, up2, out=tgt, accumulate=True)
+                else:
+                    dw = conv_wgrad_planes(xp, dyp, B, Ci, H, W, Co, KS, up2)
             else:
-                dw = conv_wgrad_raw(x, dy, B, Ci, H, W, Co, KS, up2)
+                if x is None:
+                    raise abi.HipExtensionError("Conv2dFn.backward: conv math mode changed between forward and backward")
+                if tgt is not None:
+                    conv_wgrad_raw(x, dy, B, Ci, H, W, Co, KS, up2, out=tgt, accumulate=True)
+                else:
+                    dw = conv_wgrad_raw(x, dy, B, Ci, H, W, Co, KS, up2)
         if has_bias and ctx.needs_input_grad[2]:
             db = bias_grad_raw(dy, B, Co, H * W, _grad_target(bias))
         return dx, dw, db, None
