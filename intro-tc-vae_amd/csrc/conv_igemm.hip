@@ -1013,19 +1013,33 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_wgrad_kernel(WgradArgs a) {
     const uint32_t va = kvalid ? (uint32_t)((bi * a.Co + m0 + r0) * HW + hw) * 4u : kOobBase;
 #pragma unroll
     for (int i = 0; i < AL; ++i) areg[i] = buf_load_s(rdy, va, (uint32_t)i * a_stride4);
-    uint32_t vb[TPB];
+    if constexpr (CB == 4) {
+      // <= 4 reduction channels (the 3-channel stem, or the predict conv with its operands swapped): column
+      // n = tap_local*4 + channel, this thread's columns r0 + 8i are taps 2i + (r0 >> 2) of channel r0 & 3
+      const int tsel = r0 >> 2, cl = r0 & 3;
 #pragma unroll
-    for (int tl = 0; tl < TPB; ++tl) {
-      const int tap = tap0 + tl;
-      const int hh = h + tap / KS - P, ww = w + tap % KS - P;
-      const bool valid = kvalid && tap < KK && (unsigned)hh < (unsigned)H && (unsigned)ww < (unsigned)W;
-      const int hs = UP2 ? hh >> 1 : hh, wsrc = UP2 ? ww >> 1 : ww;
-      vb[tl] = valid ? (uint32_t)(((bi * a.Ci + ci0 + r0) * Hs + hs) * Ws + wsrc) * 4u : kOobBase;
-    }
+      for (int i = 0; i < BL; ++i) {
+        const int tap = tap0 + 2 * i + tsel;
+        const int hh = h + tap / KS - P, ww = w + tap % KS - P;
+        const bool valid = kvalid && tap < KK && cl < a.Ci && (unsigned)hh < (unsigned)H && (unsigned)ww < (unsigned)W;
+        const int hs = UP2 ? hh >> 1 : hh, wsrc = UP2 ? ww >> 1 : ww;
+        breg[i] = buf_load(rx, valid ? (uint32_t)(((bi * a.Ci + cl) * Hs + hs) * Ws + wsrc) * 4u : kOobBase);
+      }
+    } else {
+      uint32_t vb[TPB];
 #pragma unroll
-    for (int i = 0; i < BL; ++i) {
-      const int tl = (RP * i) / CB, cl = (RP * i) % CB;  // compile-time after unrolling
-      breg[i] = buf_load_s(rx, vb[tl], (uint32_t)cl * b_unit4);
+      for (int tl = 0; tl < TPB; ++tl) {
+        const int tap = tap0 + tl;
+        const int hh = h + tap / KS - P, ww = w + tap % KS - P;
+        const bool valid = kvalid && tap < KK && (unsigned)hh < (unsigned)H && (unsigned)ww < (unsigned)W;
+        const int hs = UP2 ? hh >> 1 : hh, wsrc = UP2 ? ww >> 1 : ww;
+        vb[tl] = valid ? (uint32_t)(((bi * a.Ci + ci0 + r0) * Hs + hs) * Ws + wsrc) * 4u : kOobBase;
+      }
+#pragma unroll
+      for (int i = 0; i < BL; ++i) {
+        const int tl = (RP * i) / CB, cl = (RP * i) % CB;  // compile-time after unrolling
+        breg[i] = buf_load_s(rx, vb[tl], (uint32_t)cl * b_unit4);
+      }
     }
   };
   auto store_tile = [&](int buf) {
@@ -1450,13 +1464,20 @@ __global__ void wgrad_p_reduce(const float* __restrict__ slab, float* __restrict
 }
 
 // dw[co][ci][tap] (+)= sum_s slab[s][co][column(tap, ci)]
+// swapped: the GEMM ran with the operands exchanged (rows = ci, columns = (flipped tap, co)); Co/Ci here are
+// always those of dw
 __global__ void splitk_reduce_wgrad(const float* __restrict__ slab, float* __restrict__ dw, int Co, int Ci, int KK,
-                                    int Cip, int cb, int Np, size_t slab_stride, int splits, int accumulate) {
+                                    int Cip, int cb, int Np, size_t slab_stride, int splits, int accumulate,
+                                    int swapped) {
   const size_t total = (size_t)Co * Ci * KK;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-    const int tap = (int)(i % KK);
+    int tap = (int)(i % KK);
     const size_t r = i / KK;
-    const int ci = (int)(r % Ci), co = (int)(r / Ci);
+    int ci = (int)(r % Ci), co = (int)(r / Ci);
+    if (swapped) {
+      const int tmp = ci;
+      ci = co, co = tmp, tap = KK - 1 - tap;
+    }
     int col;
     if (cb == 128) {
       const int per_tap = Cip / 128;
@@ -1532,6 +1553,8 @@ static FwdPlan plan_fwd(int B, int Ci, int H, int W, int Co, int KS) {
   return p;
 }
 
+static inline bool wgrad_swapped(int Ci, int Co) { return Co <= 4 && Ci > 4; }
+
 struct WgPlan {
   int bm, cb, cip, mt, nt, tiles, ktiles, splits, kps;
 };
@@ -1540,7 +1563,7 @@ static WgPlan plan_wgrad(int B, int Ci, int H, int W, int Co, int KS) {
   WgPlan p;
   const long long Ktot = (long long)B * H * W;
   p.bm = tile_rows_for(Co);
-  p.cb = Ci <= 16 ? 16 : (Ci <= 32 ? 32 : (Ci <= 64 ? 64 : 128));
+  p.cb = Ci <= 4 ? 4 : (Ci <= 16 ? 16 : (Ci <= 32 ? 32 : (Ci <= 64 ? 64 : 128)));
   p.cip = p.cb < 128 ? p.cb : (Ci + 127) / 128 * 128;
   p.mt = cdiv(Co, p.bm);
   p.nt = p.cb == 128 ? KS * KS * (p.cip / 128) : cdiv(KS * KS, 128 / p.cb);
@@ -1591,7 +1614,9 @@ static void launch_wgrad_bm(const WgradArgs& a, int bm, hipStream_t st) {
 }
 template <int KS, bool UP2>
 static void launch_wgrad_cb(const WgradArgs& a, int bm, int cb, hipStream_t st) {
-  if (cb == 16)
+  if (cb == 4)
+    launch_wgrad_bm<KS, 4, UP2>(a, bm, st);
+  else if (cb == 16)
     launch_wgrad_bm<KS, 16, UP2>(a, bm, st);
   else if (cb == 32)
     launch_wgrad_bm<KS, 32, UP2>(a, bm, st);
@@ -2020,7 +2045,13 @@ int itcv_conv2d_fwd_bf16p(const void* xplanes, const void* wp, const float* bias
 size_t itcv_conv2d_wgrad_workspace(int B, int Ci, int H, int W, int Co, int KS) {
   if (B <= 0 || Ci <= 0 || H <= 0 || W <= 0 || Co <= 0) return 0;
   const WgPlan p = plan_wgrad(B, Ci, H, W, Co, KS);
-  return (size_t)p.splits * Co * p.nt * 128 * sizeof(float);
+  size_t n = (size_t)p.splits * Co * p.nt * 128 * sizeof(float);
+  if (wgrad_swapped(Ci, Co)) {   // the call may run with its operands exchanged (see itcv_conv2d_wgrad)
+    const WgPlan q = plan_wgrad(B, Co, H, W, Ci, KS);
+    const size_t m = (size_t)q.splits * Ci * q.nt * 128 * sizeof(float);
+    if (m > n) n = m;
+  }
+  return n;
 }
 
 int itcv_conv2d_wgrad(const float* x, const float* dy, float* dw, int B, int Ci, int H, int W, int Co, int KS,
@@ -2028,6 +2059,17 @@ int itcv_conv2d_wgrad(const float* x, const float* dy, float* dw, int B, int Ci,
   if (int e = check_dims("itcv_conv2d_wgrad", B, Ci, H, W, Co, KS)) return e;
   ITCV_REQUIRE(x && dy && dw, "itcv_conv2d_wgrad");
   if (up2) ITCV_REQUIRE(H % 2 == 0 && W % 2 == 0, "itcv_conv2d_wgrad(up2)");
+  // Few output channels (the predict conv, 64 -> 3): exchange the operands so that the wide tensor is the
+  // GEMM's row side and the 3-channel one the gathered side (4-channel column groups):
+  //   dW[co][ci][tap] = sum_q x[ci][q] * dy[co][q - tap]  =  wgrad(x' = dy, dy' = x)[ci][co][KK-1-tap]
+  const bool swapped = !up2 && wgrad_swapped(Ci, Co);
+  const int Co_dw = Co, Ci_dw = Ci;
+  if (swapped) {
+    const float* tp = x;
+    x = dy, dy = tp;
+    const int tc = Ci;
+    Ci = Co, Co = tc;
+  }
   const WgPlan p = plan_wgrad(B, Ci, H, W, Co, KS);
   const size_t slab = (size_t)Co * p.nt * 128;
   if (!ws || ws_bytes < (size_t)p.splits * slab * sizeof(float))
@@ -2059,8 +2101,8 @@ int itcv_conv2d_wgrad(const float* x, const float* dy, float* dw, int B, int Ci,
   ITCV_CHECK_LAUNCH("itcv_conv2d_wgrad");
   const size_t dw_elems = (size_t)Co * Ci * KS * KS;
   const int blocks = (int)(cdivz(dw_elems, 256) < 2048 ? cdivz(dw_elems, 256) : 2048);
-  hipLaunchKernelGGL(splitk_reduce_wgrad, dim3(blocks), dim3(256), 0, st, static_cast<const float*>(ws), dw, Co, Ci,
-                     KS * KS, p.cip, p.cb, a.Np, slab, p.splits, accumulate);
+  hipLaunchKernelGGL(splitk_reduce_wgrad, dim3(blocks), dim3(256), 0, st, static_cast<const float*>(ws), dw, Co_dw,
+                     Ci_dw, KS * KS, p.cip, p.cb, a.Np, slab, p.splits, accumulate, swapped ? 1 : 0);
   ITCV_CHECK_LAUNCH("itcv_conv2d_wgrad(reduce)");
   return 0;
 }
@@ -2111,7 +2153,7 @@ int itcv_conv2d_wgrad_bf16s(const float* x, const float* dy, float* dw, int B, i
   const size_t dw_elems = (size_t)Co * Ci * KS * KS;
   const int blocks = (int)(cdivz(dw_elems, 256) < 2048 ? cdivz(dw_elems, 256) : 2048);
   hipLaunchKernelGGL(splitk_reduce_wgrad, dim3(blocks), dim3(256), 0, st, static_cast<const float*>(ws), dw, Co, Ci,
-                     KS * KS, p.cip, p.cb, a.Np, slab, p.splits, accumulate);
+                     KS * KS, p.cip, p.cb, a.Np, slab, p.splits, accumulate, 0);
   ITCV_CHECK_LAUNCH("itcv_conv2d_wgrad_bf16s(reduce)");
   return 0;
 }
