@@ -149,7 +149,12 @@ int itcv_bn_eval_stats(const float* running_mean, const float* running_var, floa
  * added before the activation (ResidualBlock, models.py:113-114). */
 int itcv_bn_act_fwd(const float* x, const float* mean, const float* rstd, const float* gamma,
                     const float* beta, const float* skip, float* y, int B, int C, int H, int W,
-                    float slope, int pool, void* stream);
+                    float slope, int pool, void* planes, int ns, void* stream);
+/* `planes` (may be NULL): the same launch also writes the output as pre-split bf16 planes
+ * [ns][B][C/8][Ho][Wo] for the consumer conv (itcv_conv2d_fwd_bf16p / _wgrad_bf16p); needs
+ * itcv_bn_act_planes_supported(C, H, W, pool).  The fp32 output is bitwise unchanged.  The same holds
+ * for `dx_planes` of itcv_bn_act_bwd_apply (planes of dx, pool = 0 in the support query). */
+int itcv_bn_act_planes_supported(int C, int H, int W, int pool);
 /* backward, stage 1: dsums[0..C) = sum g, dsums[C..2C) = sum g*xhat where
  * g = unpool(dy) * lrelu'(bn_out (+skip)); `up2`!=0 means dy is the gradient of the x2-upsampled
  * output (dy [B][C][2H][2W], summed 2x2 on the fly: adjoint of models.py:284-286).  When non-NULL,
@@ -166,7 +171,7 @@ int itcv_bn_act_bwd_apply(const float* x, const float* dy, const float* mean, co
                           const float* gamma, const float* beta, const float* skip, const double* dsums,
                           const double* local_dsums, double count, float* dx, float* dskip,
                           float* dgamma, float* dbeta, int accumulate, int B, int C, int H, int W,
-                          float slope, int pool, int up2, void* stream);
+                          float slope, int pool, int up2, void* dx_planes, int ns, void* stream);
 
 /* ---- pointwise / resampling ----------------------------------------------------------- */
 int itcv_lrelu_fwd(const float* x, float* y, size_t n, float slope, void* stream);     /* models.py:271 */

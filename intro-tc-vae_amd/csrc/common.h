@@ -74,6 +74,27 @@ __device__ __forceinline__ float buf_load(__amdgpu_buffer_rsrc_t r, uint32_t byt
 }
 constexpr uint32_t kOOB = 0xFFFFFFFFu;
 
+// ---- split-bf16 operands: x = sum_p plane_p(x), each plane a bf16; 8 values -> one 16-byte chunk per plane
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+template <int NS>
+__device__ __forceinline__ void split8(const float (&v)[8], u32x4 (&out)[NS]) {
+  bf16x8 pl[NS];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    float r = v[j];
+#pragma unroll
+    for (int p = 0; p < NS; ++p) {
+      const __bf16 b = (__bf16)r;
+      pl[p][j] = b;
+      r -= (float)b;
+    }
+  }
+#pragma unroll
+  for (int p = 0; p < NS; ++p) out[p] = __builtin_bit_cast(u32x4, pl[p]);
+}
+
 // ---- optional per-launch timing of the GEMM-class kernels (bench.py's roofline leg) ------------
 // When enabled, a HIP event pair is recorded on the launch stream immediately around the MAIN kernel
 // of a conv call (not its split-K reduce), tagged with the kernel family / template parameters and the

@@ -252,8 +252,6 @@ __global__ void pack_weight_kernel(const float* __restrict__ w, float* __restric
 // Same tap-major K order (32 channels of one tap per K-tile), same tile/XCD mapping and epilogue as
 // the fp32 kernel.  LDS holds 16-byte chunks [plane][k/8][row] so that every MFMA fragment is one
 // conflict-free ds_read_b128.
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 // LDS-DMA of one 16-byte chunk per lane (global -> LDS at lds_base + lane*16), issued as raw ISA: the
 // compiler's own tracking of the builtin puts an `s_waitcnt vmcnt(0)` in front of EVERY later ds_read
@@ -287,23 +285,6 @@ struct ConvArgsB {
   size_t slab_stride;
   int ablate;  // diagnostic only (ITCV_ABLATE): 1 no gathers, 2 no split, 4 no weight DMA, 8 no MFMA, 16 no B stores
 };
-
-template <int NS>
-__device__ __forceinline__ void split8(const float (&v)[8], u32x4 (&out)[NS]) {
-  bf16x8 pl[NS];
-#pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    float r = v[j];
-#pragma unroll
-    for (int p = 0; p < NS; ++p) {
-      const __bf16 b = (__bf16)r;
-      pl[p][j] = b;
-      r -= (float)b;
-    }
-  }
-#pragma unroll
-  for (int p = 0; p < NS; ++p) out[p] = __builtin_bit_cast(u32x4, pl[p]);
-}
 
 template <int KS, int BM, int BN, int WM, int WN, bool UP2, int NS>
 __global__ __launch_bounds__(WM* WN * 64) void conv_fwd_bf16s_kernel(ConvArgsB a) {

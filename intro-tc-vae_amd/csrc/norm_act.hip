@@ -191,6 +191,73 @@ __global__ void bn_act_fwd_kernel(const float* __restrict__ x, const float* __re
   }
 }
 
+// Same pass, additionally emitting the output as pre-split bf16 planes for the consumer conv
+// (planes[p][b][c/8][h][w], see include/itcv_hip.h): a thread owns 8 channels x 4 output pixels (POOL = 0) or
+// x 2 pooled pixels (POOL = 1), so each pixel's 8 channel values meet in one thread.  The fp32 output is
+// computed with exactly the expressions of bn_act_fwd_kernel (bitwise the same tensor).
+template <int POOL, int NS>
+__global__ void bn_act_fwd_planes_kernel(const float* __restrict__ x, const float* __restrict__ mean,
+                                         const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                         const float* __restrict__ beta, const float* __restrict__ skip,
+                                         float* __restrict__ y, u32x4* __restrict__ planes, int B, int C, int H, int W,
+                                         float slope) {
+  const int HW = H * W, C8 = C >> 3;
+  const int Ho = POOL ? H / 2 : H, Wo = POOL ? W / 2 : W, HWo = Ho * Wo;
+  constexpr int PX = POOL ? 2 : 4;                      // output pixels per thread
+  const uint32_t per_plane = (uint32_t)HWo / PX, total = (uint32_t)B * C8 * per_plane;
+  const size_t plane_stride = (size_t)B * C8 * HWo;
+  for (uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+    const uint32_t bc8 = idx / per_plane, pp = idx - bc8 * per_plane;
+    const uint32_t b = bc8 / C8, c8 = bc8 - b * C8;
+    float o[8][PX];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int c = c8 * 8 + j;
+      const float sc = gamma[c] * rstd[c], sh = beta[c] - mean[c] * sc;
+      const size_t bc = (size_t)b * C + c;
+      if (POOL == 0) {
+        const size_t i = bc * HW + (size_t)pp * 4;
+        float4 v = *reinterpret_cast<const float4*>(x + i);
+        v.x = v.x * sc + sh, v.y = v.y * sc + sh, v.z = v.z * sc + sh, v.w = v.w * sc + sh;
+        if (skip) {
+          const float4 k = *reinterpret_cast<const float4*>(skip + i);
+          v.x += k.x, v.y += k.y, v.z += k.z, v.w += k.w;
+        }
+        v.x = lrelu(v.x, slope), v.y = lrelu(v.y, slope), v.z = lrelu(v.z, slope), v.w = lrelu(v.w, slope);
+        *reinterpret_cast<float4*>(y + i) = v;
+        o[j][0] = v.x, o[j][1] = v.y, o[j][POOL ? 0 : 2] = v.z, o[j][POOL ? 1 : 3] = v.w;
+      } else {
+        const uint32_t ho = (pp * 2) / Wo, wo = pp * 2 - ho * Wo;
+        const size_t src = bc * HW + (size_t)(2 * ho) * W + 2 * wo;
+        const float4 a = *reinterpret_cast<const float4*>(x + src);
+        const float4 bb = *reinterpret_cast<const float4*>(x + src + W);
+        float v0 = a.x * sc + sh, v1 = a.y * sc + sh, v2 = bb.x * sc + sh, v3 = bb.y * sc + sh;
+        float w0 = a.z * sc + sh, w1 = a.w * sc + sh, w2 = bb.z * sc + sh, w3 = bb.w * sc + sh;
+        if (skip) {
+          const float4 ka = *reinterpret_cast<const float4*>(skip + src);
+          const float4 kb = *reinterpret_cast<const float4*>(skip + src + W);
+          v0 += ka.x, v1 += ka.y, v2 += kb.x, v3 += kb.y;
+          w0 += ka.z, w1 += ka.w, w2 += kb.z, w3 += kb.w;
+        }
+        const float r0 = 0.25f * (lrelu(v0, slope) + lrelu(v1, slope) + lrelu(v2, slope) + lrelu(v3, slope));
+        const float r1 = 0.25f * (lrelu(w0, slope) + lrelu(w1, slope) + lrelu(w2, slope) + lrelu(w3, slope));
+        *reinterpret_cast<float2*>(y + bc * HWo + (size_t)pp * 2) = make_float2(r0, r1);
+        o[j][0] = r0, o[j][1] = r1;
+      }
+    }
+#pragma unroll
+    for (int px = 0; px < PX; ++px) {
+      float v8[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v8[j] = o[j][px];
+      u32x4 pl[NS];
+      split8<NS>(v8, pl);
+#pragma unroll
+      for (int p = 0; p < NS; ++p) planes[(size_t)p * plane_stride + (size_t)bc8 * HWo + (size_t)pp * PX + px] = pl[p];
+    }
+  }
+}
+
 // ------------------------------------------------------------------ backward
 // upstream gradient of the pre-activation u = bn(x) (+skip) at pixel (bc, h, w):
 //   MODE 0: dy same shape;  MODE 1: dy is the gradient of the 2x2-average-pooled output;
@@ -372,6 +439,59 @@ __global__ void bn_bwd_apply_v4(const float* __restrict__ x, const float* __rest
   }
 }
 
+// bn_bwd_apply_v4 that also emits dx as pre-split planes (for the data- and weight-gradient GEMMs of the conv
+// below): a thread owns 8 channels x 4 pixels; dx is computed with the same expressions (bitwise equal).
+template <int MODE, int NS>
+__global__ void bn_bwd_apply_planes(const float* __restrict__ x, const float* __restrict__ dy,
+                                    const float* __restrict__ mean, const float* __restrict__ rstd,
+                                    const float* __restrict__ gamma, const float* __restrict__ beta,
+                                    const float* __restrict__ skip, const double* __restrict__ dsums, double count,
+                                    float* __restrict__ dx, float* __restrict__ dskip, u32x4* __restrict__ planes,
+                                    int B, int C, int H, int W, float slope, int w_shift) {
+  const uint32_t HW = H * W, C8 = C >> 3, per_plane = HW / 4, total = (uint32_t)B * C8 * per_plane;
+  const size_t plane_stride = (size_t)B * C8 * HW;
+  for (uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+    const uint32_t bc8 = idx / per_plane, p4 = idx - bc8 * per_plane;
+    const uint32_t b = bc8 / C8, c8 = bc8 - b * C8;
+    const uint32_t hw = p4 * 4, h = fdiv(hw, W, w_shift), w = hw - h * W;
+    float o[8][4];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const uint32_t c = c8 * 8 + j, bc = b * C + c;
+      const uint32_t i = bc * HW + hw;
+      const float mu = mean[c], rs = rstd[c], ga = gamma[c], be = beta[c];
+      const float m1 = (float)(dsums[c] / count), m2 = (float)(dsums[C + c] / count), gr = ga * rs;
+      const float4 xv = *reinterpret_cast<const float4*>(x + i);
+      float4 g = upstream4<MODE>(dy, bc, h, w, H, W);
+      const float xh0 = (xv.x - mu) * rs, xh1 = (xv.y - mu) * rs, xh2 = (xv.z - mu) * rs, xh3 = (xv.w - mu) * rs;
+      float u0 = xh0 * ga + be, u1 = xh1 * ga + be, u2 = xh2 * ga + be, u3 = xh3 * ga + be;
+      if (skip) {
+        const float4 k = *reinterpret_cast<const float4*>(skip + i);
+        u0 += k.x, u1 += k.y, u2 += k.z, u3 += k.w;
+      }
+      if (!(u0 > 0.f)) g.x *= slope;
+      if (!(u1 > 0.f)) g.y *= slope;
+      if (!(u2 > 0.f)) g.z *= slope;
+      if (!(u3 > 0.f)) g.w *= slope;
+      const float4 d = make_float4(gr * (g.x - m1 - xh0 * m2), gr * (g.y - m1 - xh1 * m2), gr * (g.z - m1 - xh2 * m2),
+                                   gr * (g.w - m1 - xh3 * m2));
+      *reinterpret_cast<float4*>(dx + i) = d;
+      if (dskip) *reinterpret_cast<float4*>(dskip + i) = g;
+      o[j][0] = d.x, o[j][1] = d.y, o[j][2] = d.z, o[j][3] = d.w;
+    }
+#pragma unroll
+    for (int px = 0; px < 4; ++px) {
+      float v8[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v8[j] = o[j][px];
+      u32x4 pl[NS];
+      split8<NS>(v8, pl);
+#pragma unroll
+      for (int p = 0; p < NS; ++p) planes[(size_t)p * plane_stride + (size_t)bc8 * HW + hw + px] = pl[p];
+    }
+  }
+}
+
 __global__ void bn_param_grad_kernel(const double* __restrict__ local, float* dgamma, float* dbeta, int C,
                                      int accumulate) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -535,10 +655,34 @@ int itcv_bn_eval_stats(const float* running_mean, const float* running_var, floa
   return 0;
 }
 
+int itcv_bn_act_planes_supported(int C, int H, int W, int pool) {
+  return C > 0 && (C & 7) == 0 && H > 0 && W > 0 && W % 4 == 0 && (!pool || H % 2 == 0);
+}
+
 int itcv_bn_act_fwd(const float* x, const float* mean, const float* rstd, const float* gamma, const float* beta,
-                    const float* skip, float* y, int B, int C, int H, int W, float slope, int pool, void* stream) {
+                    const float* skip, float* y, int B, int C, int H, int W, float slope, int pool, void* planes,
+                    int ns, void* stream) {
   ITCV_REQUIRE(x && mean && rstd && gamma && beta && y && B > 0 && C > 0 && H > 0 && W > 0, "itcv_bn_act_fwd");
   ITCV_REQUIRE((size_t)B * C * H * W < (1ull << 31), "itcv_bn_act_fwd(tensor < 2^31 elements)");
+  if (planes) {
+    ITCV_REQUIRE((ns == 2 || ns == 3) && itcv_bn_act_planes_supported(C, H, W, pool), "itcv_bn_act_fwd(planes)");
+    const size_t threads = (size_t)B * (C / 8) * ((pool ? (H / 2) * (W / 2) : H * W) / (pool ? 2 : 4));
+    const dim3 grid(grid_for(threads)), blk(256);
+    u32x4* pl = static_cast<u32x4*>(planes);
+#define ITCV_FWD_PLANES(POOL_, NS_)                                                                                   \
+  hipLaunchKernelGGL((bn_act_fwd_planes_kernel<POOL_, NS_>), grid, blk, 0, S(stream), x, mean, rstd, gamma, beta, skip, \
+                     y, pl, B, C, H, W, slope)
+    if (pool) {
+      if (ns == 2) ITCV_FWD_PLANES(1, 2);
+      else ITCV_FWD_PLANES(1, 3);
+    } else {
+      if (ns == 2) ITCV_FWD_PLANES(0, 2);
+      else ITCV_FWD_PLANES(0, 3);
+    }
+#undef ITCV_FWD_PLANES
+    ITCV_CHECK_LAUNCH("itcv_bn_act_fwd(planes)");
+    return 0;
+  }
   if (pool) {
     ITCV_REQUIRE(H % 2 == 0 && W % 2 == 0, "itcv_bn_act_fwd(pool)");
     const size_t nout = (size_t)B * C * (H / 2) * (W / 2);
@@ -599,7 +743,7 @@ int itcv_bn_act_bwd_reduce(const float* x, const float* dy, const float* mean, c
 int itcv_bn_act_bwd_apply(const float* x, const float* dy, const float* mean, const float* rstd, const float* gamma,
                           const float* beta, const float* skip, const double* dsums, const double* local_dsums,
                           double count, float* dx, float* dskip, float* dgamma, float* dbeta, int accumulate, int B,
-                          int C, int H, int W, float slope, int pool, int up2, void* stream) {
+                          int C, int H, int W, float slope, int pool, int up2, void* dx_planes, int ns, void* stream) {
   ITCV_REQUIRE(x && dy && mean && rstd && gamma && beta && dsums && dx && B > 0 && C > 0 && count > 0,
                "itcv_bn_act_bwd_apply");
   ITCV_REQUIRE(!(pool && up2), "itcv_bn_act_bwd_apply(pool and up2 are exclusive)");
@@ -607,6 +751,31 @@ int itcv_bn_act_bwd_apply(const float* x, const float* dy, const float* mean, co
   const bool vec = (W % 4 == 0) && (n < (1ull << 31));
   const int wsh = ilog2_exact(W), hwsh = ilog2_exact(H * W), cmask = ilog2_exact(C) >= 0 ? C - 1 : -1;
   hipStream_t st = S(stream);
+  if (dx_planes) {
+    ITCV_REQUIRE((ns == 2 || ns == 3) && vec && itcv_bn_act_planes_supported(C, H, W, 0), "itcv_bn_act_bwd_apply(planes)");
+    const dim3 grid(grid_for(n / 32)), blk(256);
+    u32x4* pl = static_cast<u32x4*>(dx_planes);
+#define ITCV_BWD_PLANES(MODE_, NS_)                                                                              \
+  hipLaunchKernelGGL((bn_bwd_apply_planes<MODE_, NS_>), grid, blk, 0, st, x, dy, mean, rstd, gamma, beta, skip, dsums, \
+                     count, dx, dskip, pl, B, C, H, W, slope, wsh)
+#define ITCV_BWD_PLANES_NS(MODE_)        \
+  do {                                   \
+    if (ns == 2) ITCV_BWD_PLANES(MODE_, 2); \
+    else ITCV_BWD_PLANES(MODE_, 3);      \
+  } while (0)
+    if (pool) ITCV_BWD_PLANES_NS(1);
+    else if (up2) ITCV_BWD_PLANES_NS(2);
+    else ITCV_BWD_PLANES_NS(0);
+#undef ITCV_BWD_PLANES_NS
+#undef ITCV_BWD_PLANES
+    ITCV_CHECK_LAUNCH("itcv_bn_act_bwd_apply(planes)");
+    if (dgamma || dbeta) {
+      hipLaunchKernelGGL(bn_param_grad_kernel, dim3(cdiv(C, 256)), dim3(256), 0, st, local_dsums ? local_dsums : dsums,
+                         dgamma, dbeta, C, accumulate);
+      ITCV_CHECK_LAUNCH("itcv_bn_act_bwd_apply(param grads)");
+    }
+    return 0;
+  }
 #define ITCV_BWD_APPLY(MODE)                                                                                      \
   do {                                                                                                            \
     if (vec)                                                                                                      \

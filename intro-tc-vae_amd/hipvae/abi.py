@@ -63,11 +63,12 @@ SIGNATURES = {
     "itcv_bn_train_stats": (i32, [p, i32, i32, i32, f32, f32, p, p, p, p, p, p, sz, p]),
     "itcv_bn_finalize": (i32, [p, f64, f32, f32, p, p, p, p, p, i32, p]),
     "itcv_bn_eval_stats": (i32, [p, p, f32, p, p, i32, p]),
-    "itcv_bn_act_fwd": (i32, [p, p, p, p, p, p, p, i32, i32, i32, i32, f32, i32, p]),
+    "itcv_bn_act_planes_supported": (i32, [i32] * 4),
+    "itcv_bn_act_fwd": (i32, [p, p, p, p, p, p, p, i32, i32, i32, i32, f32, i32, p, i32, p]),
     "itcv_bn_act_bwd_reduce": (i32, [p, p, p, p, p, p, p, p, p, p, i32, i32, i32, i32, i32, f32, i32, i32, p, sz,
                                      p]),
     "itcv_bn_act_bwd_apply": (i32, [p, p, p, p, p, p, p, p, p, f64, p, p, p, p, i32, i32, i32, i32, i32, f32,
-                                    i32, i32, p]),
+                                    i32, i32, p, i32, p]),
     "itcv_lrelu_fwd": (i32, [p, p, sz, f32, p]),
     "itcv_lrelu_bwd": (i32, [p, p, p, sz, f32, p]),
     "itcv_sigmoid_fwd": (i32, [p, p, sz, p]),

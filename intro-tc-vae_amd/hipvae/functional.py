@@ -270,6 +270,47 @@ def bias_grad_raw(dy, B, C, HW, target=None):
     return None if target is not None else db
 
 
+PLANES_STATS = [0, 0]   # conv operands taken from producer-attached planes / split on demand (diagnostic)
+
+
+def _tag_planes(t, planes, ns):
+    """Attach the pre-split planes of ``t`` to the tensor object (consumed by the next conv GEMM)."""
+    t._itcv_planes = (planes, ns, t._version, t.data_ptr())
+
+
+def _tagged_planes(t, ns):
+    tag = getattr(t, "_itcv_planes", None)
+    if tag is None or tag[1] != ns or tag[2] != t._version or tag[3] != t.data_ptr():
+        return None
+    return tag[0]
+
+
+def planes_of(t, ns):
+    """Planes of ``t``: the ones its producer attached, else a split pass."""
+    p = _tagged_planes(t, ns)
+    PLANES_STATS[0 if p is not None else 1] += 1
+    return p if p is not None else split_planes(t, ns)
+
+
+def conv_input_planes_ns(conv, up2=False):
+    """ns when ``conv`` (an nn.Conv2d-like module) will read its input as planes in the current mode, else 0:
+    tells the producing BatchNorm pass to emit them."""
+    if conv is None:
+        return 0
+    return _planes_ns(conv.in_channels, conv.out_channels, conv.kernel_size[0], up2)
+
+
+def conv_grad_planes_ns(conv, needs_input_grad=True):
+    """ns when the backward of ``conv`` will read its output gradient as planes (data- and/or weight-gradient)."""
+    if conv is None:
+        return 0
+    ks = conv.kernel_size[0]
+    ns = _planes_ns(conv.out_channels, conv.in_channels, ks, False) if needs_input_grad else 0
+    if not ns and _NS[_CONV_MATH[0]] == 2 and _PLANES[0] and ks == 3:
+        ns = 2    # weight gradient on planes (shape support is re-checked where the planes are consumed)
+    return ns
+
+
 def _planes_ns(Ci, Co, KS, up2):
     """Number of bf16 planes when a forward-type conv GEMM (Ci -> Co) runs on pre-split operands, else 0."""
     ns = _NS[_CONV_MATH[0]]
@@ -301,7 +342,7 @@ class Conv2dFn(Function):
         ns = _planes_ns(Ci, Co, KS, up2)
         xp = None
         if ns:
-            xp = split_planes(x, ns)
+            xp = planes_of(x, ns)
             y = conv_apply_planes(xp, weight, weight, 0, b, B, Ci, H, W, Co, KS, up2, ns)
         else:
             y = conv_apply(x, weight, weight, 0, b, B, Ci, H, W, Co, KS, up2)
@@ -322,7 +363,7 @@ class Conv2dFn(Function):
         wg_planes = ctx.needs_input_grad[1] and _wgrad_planes_ok(B, Ci, H, W, Co, KS)
         dyp = None
         if ns_d or wg_planes:
-            dyp = split_planes(dy, ns_d if ns_d else 2)
+            dyp = planes_of(dy, ns_d if ns_d else 2)
         if ctx.needs_input_grad[0]:
             if ns_d:
                 dx = conv_apply_planes(dyp, weight, weight, 1, None, B, Co, H, W, Ci, KS, False, ns_d)
@@ -398,7 +439,7 @@ class BnActFn(Function):
 
     @staticmethod
     def forward(ctx, x, gamma, beta, skip, running_mean, running_var, nbt, eps, momentum, slope, pool, training,
-                group):
+                group, out_planes=0, grad_planes=0):
         x, gamma, beta = _f32c(x), _f32c(gamma), _f32c(beta)
         skip = None if skip is None else _f32c(skip)
         B, C, H, W = x.shape
@@ -423,11 +464,19 @@ class BnActFn(Function):
             call("itcv_bn_eval_stats", ptr(running_mean), ptr(running_var), float(eps), ptr(mean), ptr(rstd), C, stream())
         oshape = (B, C, H // 2, W // 2) if pool else (B, C, H, W)
         y = torch.empty(oshape, dtype=F32, device=dev)
+        yp = None
+        if out_planes and lib.itcv_bn_act_planes_supported(C, H, W, int(pool)):
+            yp = torch.empty(lib.itcv_planes_bytes(B, C, oshape[2] * oshape[3], out_planes) // 4, dtype=torch.int32,
+                             device=dev)
         call("itcv_bn_act_fwd", ptr(x), ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), ptr(skip), ptr(y), B, C, H, W,
-             float(slope), int(pool), stream())
+             float(slope), int(pool), ptr(yp), int(out_planes), stream())
+        if yp is not None:
+            _tag_planes(y, yp, out_planes)
         ctx.save_for_backward(x, gamma, beta, mean, rstd, skip)
         ctx.params = (gamma, beta)
-        ctx.cfg = (B, C, H, W, float(slope), int(pool), bool(training), group, world)
+        if not lib.itcv_bn_act_planes_supported(C, H, W, 0):
+            grad_planes = 0
+        ctx.cfg = (B, C, H, W, float(slope), int(pool), bool(training), group, world, int(grad_planes))
         ctx.mark_non_differentiable(*[t for t in (running_mean, running_var, nbt) if t is not None])
         return y
 
@@ -435,7 +484,7 @@ class BnActFn(Function):
     @once_differentiable
     def backward(ctx, dy):
         x, gamma, beta, mean, rstd, skip = ctx.saved_tensors
-        B, C, H, W, slope, pool, training, group, world = ctx.cfg
+        B, C, H, W, slope, pool, training, group, world, grad_planes = ctx.cfg
         if not training:
             raise abi.HipExtensionError("BatchNorm backward in eval mode is not part of the training hot path")
         dy = _f32c(dy)
@@ -463,10 +512,15 @@ class BnActFn(Function):
             dist.all_reduce(total, group=group)
         dx = torch.empty_like(x)
         dskip = torch.empty_like(x) if (skip is not None and ctx.needs_input_grad[3]) else None
+        dxp = None
+        if grad_planes:
+            dxp = torch.empty(lib.itcv_planes_bytes(B, C, H * W, grad_planes) // 4, dtype=torch.int32, device=dev)
         call("itcv_bn_act_bwd_apply", ptr(x), ptr(dy), ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), ptr(skip),
              ptr(total), None, float(B * H * W * world), ptr(dx), ptr(dskip), None, None, 0, B, C, H,
-             W, slope, pool, 0, stream())
-        return (dx, dgamma, dbeta, dskip) + (None,) * 9
+             W, slope, pool, 0, ptr(dxp), grad_planes, stream())
+        if dxp is not None:
+            _tag_planes(dx, dxp, grad_planes)
+        return (dx, dgamma, dbeta, dskip) + (None,) * 11
 
 
 # ------------------------------------------------------------------ pointwise / resampling

@@ -44,10 +44,12 @@ class HipBatchNorm2d(nn.BatchNorm2d):
 
     sync_group = None
 
-    def forward(self, x, slope=1.0, pool=False, skip=None):
+    def forward(self, x, slope=1.0, pool=False, skip=None, out_planes=0, grad_planes=0):
+        """``out_planes`` / ``grad_planes``: number of bf16 planes in which the output / the input gradient are
+        additionally written for the neighbouring conv GEMMs (0 = not at all); see hipvae.functional."""
         return HF.BnActFn.apply(x, self.weight, self.bias, skip, self.running_mean, self.running_var,
                                 self.num_batches_tracked, self.eps, self.momentum, slope, bool(pool), self.training,
-                                self.sync_group)
+                                self.sync_group, int(out_planes), int(grad_planes))
 
 
 class HipLeakyReLU(nn.LeakyReLU):
@@ -97,9 +99,13 @@ class ConvolutionalBlock(nn.Module):
         self.bn2 = HipBatchNorm2d(outc, eps=self.eps)
         self.relu2 = HipLeakyReLU(LRELU_SLOPE, inplace=True)
 
-    def forward(self, x, pool=False, up2=False):
-        y = self.bn1(self.conv1(x, up2=up2), slope=LRELU_SLOPE)
-        return self.bn2(self.conv2(y), slope=LRELU_SLOPE, pool=pool)
+    def forward(self, x, pool=False, up2=False, consumer=None, consumer_up2=False):
+        """``consumer``: the conv module that reads this block's output (its planes are emitted by bn2)."""
+        y = self.bn1(self.conv1(x, up2=up2), slope=LRELU_SLOPE, out_planes=HF.conv_input_planes_ns(self.conv2),
+                     grad_planes=HF.conv_grad_planes_ns(self.conv1, x.requires_grad))
+        return self.bn2(self.conv2(y), slope=LRELU_SLOPE, pool=pool,
+                        out_planes=HF.conv_input_planes_ns(consumer, consumer_up2),
+                        grad_planes=HF.conv_grad_planes_ns(self.conv2))
 
 
 class ResidualBlock(nn.Module):
@@ -118,13 +124,16 @@ class ResidualBlock(nn.Module):
         self.bn2 = HipBatchNorm2d(outc)
         self.relu2 = HipLeakyReLU(LRELU_SLOPE, inplace=True)
 
-    def forward(self, x, pool=False, up2=False):
+    def forward(self, x, pool=False, up2=False, consumer=None, consumer_up2=False):
         if self.conv_expand is not None:
             skip = self.conv_expand(x, up2=up2)
         else:
             skip = HF.Upsample2Fn.apply(x) if up2 else x
-        y = self.bn1(self.conv1(x, up2=up2), slope=LRELU_SLOPE)
-        return self.bn2(self.conv2(y), slope=LRELU_SLOPE, pool=pool, skip=skip)
+        y = self.bn1(self.conv1(x, up2=up2), slope=LRELU_SLOPE, out_planes=HF.conv_input_planes_ns(self.conv2),
+                     grad_planes=HF.conv_grad_planes_ns(self.conv1, x.requires_grad))
+        return self.bn2(self.conv2(y), slope=LRELU_SLOPE, pool=pool, skip=skip,
+                        out_planes=HF.conv_input_planes_ns(consumer, consumer_up2),
+                        grad_planes=HF.conv_grad_planes_ns(self.conv2))
 
 
 class Conv2dBatchNorm(nn.Module):
@@ -160,7 +169,7 @@ class InceptionResnetBlock(nn.Module):
         self.conv = _conv(outc, outc, 1, bias=True)
         self.relu = HipLeakyReLU(LRELU_SLOPE, inplace=True)
 
-    def forward(self, x, pool=False, up2=False):
+    def forward(self, x, pool=False, up2=False, consumer=None, consumer_up2=False):
         if up2:
             x = HF.Upsample2Fn.apply(x)
         skip = self.conv_expand(x) if self.conv_expand is not None else x
@@ -226,9 +235,13 @@ class Encoder(nn.Module):
 
     def forward(self, x):
         if self.fused:
-            y = self.main[1](self.main[0](x), slope=LRELU_SLOPE, pool=True)
-            for name, pooled in self._stages:
-                y = getattr(self.main, name)(y, pool=pooled)
+            blocks = [getattr(self.main, name) for name, _ in self._stages]
+            y = self.main[1](self.main[0](x), slope=LRELU_SLOPE, pool=True,
+                             out_planes=HF.conv_input_planes_ns(blocks[0].conv1),
+                             grad_planes=HF.conv_grad_planes_ns(self.main[0], x.requires_grad))
+            for k, (name, pooled) in enumerate(self._stages):
+                nxt = blocks[k + 1].conv1 if k + 1 < len(blocks) else None
+                y = blocks[k](y, pool=pooled, consumer=nxt)
         else:
             y = self.main(x)
         y = self.fc(y.reshape(x.size(0), -1))
@@ -268,8 +281,10 @@ class Decoder(nn.Module):
         z = z.reshape(z.size(0), -1)
         y = self.fc(z).view(z.size(0), *self.conv_input_size)
         if self.fused:
-            for k, name in enumerate(self._stages):
-                y = getattr(self.main, name)(y, up2=k > 0)  # the upsample before block k folds into its conv
+            blocks = [getattr(self.main, name) for name in self._stages]
+            for k, blk in enumerate(blocks):   # the upsample before block k folds into its conv
+                nxt = blocks[k + 1].conv1 if k + 1 < len(blocks) else self.main.predict
+                y = blk(y, up2=k > 0, consumer=nxt, consumer_up2=k + 1 < len(blocks))
             y = self.main.sigmoid(self.main.predict(y))
         else:
             y = self.main(y)

@@ -204,7 +204,7 @@ def test_bn_upsampled_gradient_mode(HF):
              None, None, 0, B, C, H, W, 0.2, 0, up2, ptr(ws), nws, stream())
         dx = torch.empty_like(x)
         call("itcv_bn_act_bwd_apply", ptr(x), ptr(dy), ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), None, ptr(sums),
-             None, float(B * H * W), ptr(dx), None, None, None, 0, B, C, H, W, 0.2, 0, up2, stream())
+             None, float(B * H * W), ptr(dx), None, None, None, 0, B, C, H, W, 0.2, 0, up2, None, 0, stream())
         outs.append((sums.clone(), dx))
     assert rel_err(outs[0][0], outs[1][0]) < 1e-6
     assert rel_err(outs[0][1], outs[1][1]) < 1e-5
