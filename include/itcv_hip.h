@@ -78,10 +78,11 @@ int itcv_conv2d_fwd_bf16s(const float* x, const void* wp, const float* bias, flo
  * channels c..c+7 of one pixel (C % 8 == 0; p < ns).  A producing pass (itcv_split_planes, or the
  * BatchNorm apply / backward kernels through their `planes` argument) writes it next to the fp32
  * tensor; itcv_conv2d_fwd_bf16p then moves both operands global -> LDS by LDS-DMA (no gather, no
- * conversion in the conv kernel).  Same contract, shapes, workspace and -- bit for bit -- results as
+ * conversion in the conv kernel).  Same contract and shapes (its own workspace query) and -- bit for bit -- results as
  * itcv_conv2d_fwd_bf16s (replaces the same ATen conv forward / data-gradient, models.py:28-47). */
 size_t itcv_planes_bytes(int B, int C, int HW, int ns);
 int itcv_split_planes(const float* x, void* planes, int B, int C, int HW, int ns, void* stream);
+size_t itcv_conv2d_fwd_bf16p_workspace(int B, int Ci, int H, int W, int Co, int KS, int ns);
 int itcv_conv2d_fwd_bf16p(const void* xplanes, const void* wp, const float* bias, float* y, int B, int Ci, int H,
                           int W, int Co, int KS, int up2, int ns, void* ws, size_t ws_bytes, void* stream);
 /* Weight gradient from the same planes (x: [2][B][Ci/8][Hs][Ws], dy: [2][B][Co/8][H][W]); the pixel

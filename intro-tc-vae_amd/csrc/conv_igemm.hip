@@ -878,6 +878,201 @@ __global__ __launch_bounds__(512) void conv_fwd_bf16p_kernel(ConvArgsP a) {
   }
 }
 
+// ---- second form of the planes kernel: tap reuse through LDS ---------------------------------------
+// conv_fwd_bf16p_kernel fetches every input chunk nine times (once per tap) and its weight tile once per
+// 128 pixels; measured, the L2 -> LDS ingest (~30 B/clk/CU) then takes as long as the MFMAs.  Here a block
+// owns 256 consecutive pixels (a band of whole image rows) x BM output channels:
+//   * per 32-channel group the band arrives ONCE, with its halo (rows -1..NR, columns -1..W, zero chunks
+//     outside the image), double-buffered; the nine taps read it at fragment addresses shifted by
+//     dh*(W+2)+dw chunks -- no per-tap traffic at all;
+//   * the weight tile of each (group, tap) streams through a 3-slot ring and serves twice the pixels;
+//   * 8 MFMA waves (two per SIMD, so one fills the other's barrier / LDS-latency bubbles) + 4 loader waves.
+// Ingest per MFMA drops ~2.8x.  Same arithmetic and K order as the other split-bf16 kernels (bit-identical).
+struct ConvArgsP2 {
+  const u32x4* xp;
+  const u32x4* wp;
+  const float* bias;
+  float* y;
+  int B, Ci, H, Co;
+  int Mp, N;
+  int mt, nt;
+  int cpt, cpt_per_split;        // 32-channel groups, and how many of them one split-K slice takes
+  int SR, NSEG, NP, NPC, PXB;    // band geometry: segment rows, segments, halo pixels, 64-chunk pieces, LDS row stride
+  int h_shift;
+  size_t slab_stride, plane_stride;
+};
+
+template <int LOG2W, int BM, bool UP2>
+__global__ __launch_bounds__(768) void conv_fwd_bf16p2_kernel(ConvArgsP2 a) {
+  constexpr int W = 1 << LOG2W, WP = W + 2, BN = 256, KC = 4, NS = 2;
+  constexpr int WM = BM / 64, WN = 8 / WM, WTN = BN / WN, TM = 2, TN = WTN / 32;   // 128: 2x4 waves of 64x64; 64: 1x8 of 64x32
+  constexpr int ASZ = NS * KC * BM;                // chunks per weight tile
+  constexpr int PA = NS * KC * BM / 64 / 4;        // weight pieces per loader wave per K-tile
+  extern __shared__ u32x4 smem[];                  // [3][ASZ] weight ring, then [2][NS*KC*PXB] bands
+
+  const int t = threadIdx.x, lane = t & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int bid = blockIdx.x, xcd = bid & 7, q = bid >> 3;
+  const int tile_m = q % a.mt, tile_n = (q / a.mt) * 8 + xcd;
+  if (tile_n >= a.nt) return;
+  const int sk = blockIdx.y;
+  const int c0 = sk * a.cpt_per_split, c1 = min(a.cpt, c0 + a.cpt_per_split);
+  if (c0 >= c1) return;
+  const int nk = (c1 - c0) * 9;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int H = a.H, HW = H << LOG2W;
+  const int PXB = a.PXB, BSZ = NS * KC * PXB;
+  const uint32_t smem_base = lds_addr(smem);
+  const uint32_t band_base = smem_base + 3u * ASZ * 16u;
+
+  if (wid >= 8) {
+    // ------------------------------------------------------------------ loaders
+    const int lw = wid - 8;
+    const int Hs = UP2 ? H / 2 : H, Ws = UP2 ? W / 2 : W, HWs = Hs * Ws;
+    const int C8 = a.Ci >> 3;
+    const u32x4* zero = &g_zero_chunk;
+    // band pieces of this wave: rows pk = lw (plane 0, kc = lw) and lw + 4 (plane 1), halo pixels q*64 + lane
+    const int R0 = n0 >> LOG2W, seg_px = (a.SR + 2) * WP;
+    long long soff[8];
+    uint32_t vmask = 0;
+#pragma unroll
+    for (int qq = 0; qq < 8; ++qq) {
+      const int hp = qq * 64 + lane;   // lanes past NP land in the row's padding (PXB = NPC*64) and read zeros
+      soff[qq] = 0;
+      if (qq < a.NPC && hp < a.NP) {
+        const int seg = hp / seg_px, rem = hp - seg * seg_px, hr = rem / WP, hc = rem - hr * WP;
+        const int grow = R0 + seg * a.SR, b = grow >> a.h_shift, h = (grow & (H - 1)) + hr - 1, wv = hc - 1;
+        if (b < a.B && (unsigned)h < (unsigned)H && (unsigned)wv < (unsigned)W) {
+          vmask |= 1u << qq;
+          soff[qq] = (long long)b * C8 * HWs + (UP2 ? (h >> 1) * Ws + (wv >> 1) : h * W + wv);
+        }
+      }
+    }
+    // every wave instruction below is issued by all 64 lanes (never skipped): the counted vmcnt waits rely on it
+    auto issue_band_piece = [&](int cib, int buf, long long so, bool valid, int qq) {
+#pragma unroll
+      for (int pl = 0; pl < NS; ++pl) {
+        const u32x4* src = a.xp + ((size_t)pl * a.plane_stride + (size_t)(cib * KC + lw) * HWs + so);
+        lds_dma16(valid ? src : zero, band_base + (uint32_t)(buf * BSZ + (pl * KC + lw) * PXB + qq * 64) * 16u);
+      }
+    };
+    auto issue_A = [&](int i, int slot) {   // weight tile of K-tile i of this slice
+      const int kt = c0 * 9 + i;
+      const u32x4* wt = a.wp + (size_t)kt * NS * KC * a.Mp + m0 + lane;
+      const uint32_t sbase = smem_base + (uint32_t)(slot * ASZ) * 16u;
+#pragma unroll
+      for (int j = 0; j < PA; ++j) {
+        const int piece = j * 4 + lw, mlc = piece % (BM / 64), pk = piece / (BM / 64);
+        lds_dma16(wt + (size_t)pk * a.Mp + mlc * 64, sbase + (uint32_t)(pk * BM + mlc * 64) * 16u);
+      }
+    };
+#pragma unroll
+    for (int qq = 0; qq < 8; ++qq)
+      if (qq < a.NPC) issue_band_piece(c0, 0, soff[qq], (vmask >> qq) & 1u, qq);
+    issue_A(0, 0);
+    issue_A(min(1, nk - 1), 1);
+    wait_vmcnt<PA>();                                    // band and tile 0 landed; tile 1 may be in flight
+    __builtin_amdgcn_s_barrier();
+    int buf = 0;
+    for (int cib = c0; cib < c1; ++cib) {
+      const int ib = (cib - c0) * 9;
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        issue_A(min(ib + tap + 2, nk - 1), (tap + 2) % 3);   // into the slot K-tile i-1 has just left
+        // next group's band, one piece (x 2 planes) per tap
+        if (tap < 8 && tap < a.NPC && cib + 1 < c1) {
+          issue_band_piece(cib + 1, buf ^ 1, soff[tap < 8 ? tap : 0], (vmask >> tap) & 1u, tap);
+          wait_vmcnt<PA + NS>();                           // K-tile i+1's weights (and everything older) have landed
+        } else {
+          wait_vmcnt<PA>();
+        }
+        __builtin_amdgcn_s_barrier();
+      }
+      buf ^= 1;
+    }
+    return;
+  }
+
+  // -------------------------------------------------------------------- MFMA waves
+  const int wm = wid / WN, wn = wid % WN, l31 = lane & 31, half = lane >> 5;
+  // band index of this lane's pixel of N-tile j (centre tap)
+  uint32_t hoff[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int nl = wn * WTN + j * 32 + l31, R = nl >> LOG2W, w = nl & (W - 1);
+    const int seg = R / a.SR, rr = R - seg * a.SR;
+    hoff[j] = (uint32_t)((seg * (a.SR + 2) + rr + 1) * WP + w + 1) * 16u;
+  }
+  const uint32_t aoff = (uint32_t)(wm * 64 + l31) * 16u;
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  __builtin_amdgcn_s_barrier();
+  int buf = 0;
+  for (int cib = c0; cib < c1; ++cib) {
+    const uint32_t bb = band_base + (uint32_t)(buf * BSZ) * 16u;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int tapoff = ((tap / 3 - 1) * WP + (tap % 3 - 1)) * 16;
+      const uint32_t ab = smem_base + (uint32_t)((tap % 3) * ASZ) * 16u + aoff;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const int kc = ks * 2 + half;
+        bf16x8 af[NS][TM], bfr[NS][TN];
+#pragma unroll
+        for (int pp = 0; pp < NS; ++pp) {
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+            af[pp][i] = __builtin_bit_cast(
+                bf16x8, *(const __attribute__((address_space(3))) u32x4*)(size_t)(ab + (uint32_t)(((pp * KC + kc) * BM + i * 32) * 16)));
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            bfr[pp][j] = __builtin_bit_cast(
+                bf16x8, *(const __attribute__((address_space(3))) u32x4*)(size_t)(bb + (uint32_t)((pp * KC + kc) * PXB) * 16u + hoff[j] + tapoff));
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) {
+            f32x16 c = acc[i][j];
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bfr[1][j], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][i], bfr[0][j], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bfr[0][j], c, 0, 0, 0);
+            acc[i][j] = c;
+          }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
+    buf ^= 1;
+  }
+
+  float* out = a.y + (size_t)sk * a.slab_stride;
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int nn = n0 + wn * WTN + j * 32 + l31;
+    if (nn >= a.N) continue;
+    const int b2 = nn / HW, hw2 = nn - b2 * HW;
+    const size_t base = (size_t)b2 * a.Co * HW + hw2;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (m < a.Co) {
+          float v = acc[i][j][r];
+          if (a.bias) v += a.bias[m];
+          out[base + (size_t)m * HW] = v;
+        }
+      }
+    }
+  }
+}
+
 // fp32 NCHW -> planes[p][b][c/8][hw] (C % 8 == 0); one thread per chunk, coalesced over hw
 template <int NS>
 __global__ void split_planes_kernel(const float* __restrict__ x, u32x4* __restrict__ planes, int B, int C8, int HW) {
@@ -1716,6 +1911,75 @@ static void launch_fwd_p(const ConvArgsP& a, int bm, int splits, int up2, hipStr
   launch_fwd_p_st<KS, NS, 2>(a, bm, splits, up2, st);
 }
 
+struct FwdPlanP2 {
+  int ok, bm, mt, nt, cpt, splits, cps, SR, NSEG, NP, NPC, PXB;
+  size_t lds;
+};
+static FwdPlanP2 plan_fwd_p2(int B, int Ci, int H, int W, int Co, int KS, int ns) {
+  FwdPlanP2 p;
+  memset(&p, 0, sizeof(p));
+  const int lw = log2_exact(W), lh = log2_exact(H);
+  if (KS != 3 || ns != 2 || lw < 3 || lw > 6 || lh < 0 || Ci % 32 || Co < 33) return p;
+  static int enabled = -1;
+  if (enabled < 0) {
+    const char* e = getenv("ITCV_BF16P2");
+    enabled = (e && e[0] == '0') ? 0 : 1;
+  }
+  if (!enabled) return p;
+  const int NR = 256 / W;
+  p.SR = NR < H ? NR : H;
+  p.NSEG = NR / p.SR;
+  p.NP = p.NSEG * (p.SR + 2) * (W + 2);
+  p.NPC = cdiv(p.NP, 64);
+  p.PXB = p.NPC * 64;
+  if (p.NPC > 7) return p;
+  p.bm = Co <= 64 ? 64 : 128;
+  p.lds = ((size_t)3 * 2 * 4 * p.bm + (size_t)2 * 2 * 4 * p.PXB) * 16;
+  if (p.lds > 160 * 1024) return p;
+  p.mt = cdiv(Co, p.bm);
+  p.nt = (int)(((long long)B * H * W + 255) / 256);
+  p.cpt = Ci / 32;
+  const int tiles = p.mt * p.nt;
+  // mid-sized layers: 128-pixel tiles (conv_fwd_bf16p_kernel) already fill the chip without split-K, 256-pixel
+  // bands would not -- measured faster there
+  if (tiles < 192 && cdiv(Co, 128) * (int)(((long long)B * H * W + 127) / 128) >= 192 && Co > 64) {
+    p.ok = 0;
+    return p;
+  }
+  int splits = 1;
+  if (tiles < 192 && p.cpt >= 2) {
+    splits = 256 / tiles;
+    if (splits > p.cpt) splits = p.cpt;
+    if (splits < 1) splits = 1;
+  }
+  p.cps = cdiv(p.cpt, splits);
+  p.splits = cdiv(p.cpt, p.cps);
+  p.ok = 1;
+  return p;
+}
+
+template <int LOG2W, int BM, bool UP2>
+static void launch_fwd_p2_cfg(const ConvArgsP2& a, int splits, size_t lds, hipStream_t st) {
+  auto kern = conv_fwd_bf16p2_kernel<LOG2W, BM, UP2>;
+  static size_t attr = 0;
+  if (attr < lds) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr = lds;
+  }
+  dim3 grid(cdiv(a.nt, 8) * 8 * a.mt, splits);
+  hipLaunchKernelGGL(kern, grid, dim3(768), lds, st, a);
+}
+template <int LOG2W>
+static void launch_fwd_p2_w(const ConvArgsP2& a, int bm, int up2, int splits, size_t lds, hipStream_t st) {
+  if (bm == 64) {
+    if (up2) launch_fwd_p2_cfg<LOG2W, 64, true>(a, splits, lds, st);
+    else launch_fwd_p2_cfg<LOG2W, 64, false>(a, splits, lds, st);
+  } else {
+    if (up2) launch_fwd_p2_cfg<LOG2W, 128, true>(a, splits, lds, st);
+    else launch_fwd_p2_cfg<LOG2W, 128, false>(a, splits, lds, st);
+  }
+}
+
 struct WgPlanP {
   int tiles_m, tiles_n, steps, splits, sps;
 };
@@ -1898,6 +2162,13 @@ size_t itcv_conv2d_fwd_bf16s_workspace(int B, int Ci, int H, int W, int Co, int 
   return p.splits > 1 ? (size_t)p.splits * B * Co * H * W * sizeof(float) : 0;
 }
 
+size_t itcv_conv2d_fwd_bf16p_workspace(int B, int Ci, int H, int W, int Co, int KS, int ns) {
+  if (B <= 0 || Ci <= 0 || H <= 0 || W <= 0 || Co <= 0) return 0;
+  const FwdPlanP2 p2 = plan_fwd_p2(B, Ci, H, W, Co, KS, ns);
+  if (p2.ok) return p2.splits > 1 ? (size_t)p2.splits * B * Co * H * W * sizeof(float) : 0;
+  return itcv_conv2d_fwd_bf16s_workspace(B, Ci, H, W, Co, KS);
+}
+
 int itcv_conv2d_fwd_bf16s(const float* x, const void* wp, const float* bias, float* y, int B, int Ci, int H, int W,
                           int Co, int KS, int up2, int ns, void* ws, size_t ws_bytes, void* stream) {
   if (int e = check_dims("itcv_conv2d_fwd_bf16s", B, Ci, H, W, Co, KS)) return e;
@@ -1978,8 +2249,45 @@ int itcv_conv2d_fwd_bf16p(const void* xplanes, const void* wp, const float* bias
   if (!itcv_conv2d_bf16s_supported(Ci, Co, KS))
     return fail("%s: shape not supported by the split-bf16 kernel (Ci %% 32, Co > 32, KS 1/3)", "itcv_conv2d_fwd_bf16p");
   if (up2) ITCV_REQUIRE(H % 2 == 0 && W % 2 == 0, "itcv_conv2d_fwd_bf16p(up2)");
-  const FwdPlanB p = plan_fwd_b(B, Ci, H, W, Co, KS);
   const size_t out_elems = (size_t)B * Co * H * W;
+  const FwdPlanP2 p2 = plan_fwd_p2(B, Ci, H, W, Co, KS, ns);
+  if (p2.ok) {   // band kernel: tap reuse through LDS
+    if (p2.splits > 1 && (!ws || ws_bytes < (size_t)p2.splits * out_elems * sizeof(float)))
+      return fail("%s: workspace too small (need %lld bytes)", "itcv_conv2d_fwd_bf16p",
+                  (long long)((size_t)p2.splits * out_elems * sizeof(float)));
+    ConvArgsP2 a;
+    a.xp = static_cast<const u32x4*>(xplanes);
+    a.wp = static_cast<const u32x4*>(wp);
+    a.bias = p2.splits > 1 ? nullptr : bias;
+    a.y = p2.splits > 1 ? static_cast<float*>(ws) : y;
+    a.B = B, a.Ci = Ci, a.H = H, a.Co = Co;
+    a.Mp = p2.mt * p2.bm;
+    a.N = B * H * W;
+    a.mt = p2.mt, a.nt = p2.nt, a.cpt = p2.cpt, a.cpt_per_split = p2.cps;
+    a.SR = p2.SR, a.NSEG = p2.NSEG, a.NP = p2.NP, a.NPC = p2.NPC, a.PXB = p2.PXB;
+    a.h_shift = log2_exact(H);
+    a.slab_stride = p2.splits > 1 ? out_elems : 0;
+    a.plane_stride = (size_t)B * (Ci / 8) * (up2 ? (H / 2) * (W / 2) : H * W);
+    hipStream_t st = S(stream);
+    {
+      ProfScope prof(st, 6, KS, p2.bm, up2 ? 1 : 0, ns, 2.0 * B * H * W * (double)Co * Ci * KS * KS);
+      switch (log2_exact(W)) {
+        case 3: launch_fwd_p2_w<3>(a, p2.bm, up2, p2.splits, p2.lds, st); break;
+        case 4: launch_fwd_p2_w<4>(a, p2.bm, up2, p2.splits, p2.lds, st); break;
+        case 5: launch_fwd_p2_w<5>(a, p2.bm, up2, p2.splits, p2.lds, st); break;
+        default: launch_fwd_p2_w<6>(a, p2.bm, up2, p2.splits, p2.lds, st); break;
+      }
+    }
+    ITCV_CHECK_LAUNCH("itcv_conv2d_fwd_bf16p(band)");
+    if (p2.splits > 1) {
+      const int blocks = (int)(cdivz(out_elems, 256) < 2048 ? cdivz(out_elems, 256) : 2048);
+      hipLaunchKernelGGL(splitk_reduce_fwd, dim3(blocks), dim3(256), 0, st, static_cast<const float*>(ws), bias, y,
+                         out_elems, out_elems, p2.splits, H * W, Co);
+      ITCV_CHECK_LAUNCH("itcv_conv2d_fwd_bf16p(reduce)");
+    }
+    return 0;
+  }
+  const FwdPlanB p = plan_fwd_b(B, Ci, H, W, Co, KS);
   if (p.splits > 1 && (!ws || ws_bytes < (size_t)p.splits * out_elems * sizeof(float)))
     return fail("%s: workspace too small (need %lld bytes)", "itcv_conv2d_fwd_bf16p",
                 (long long)((size_t)p.splits * out_elems * sizeof(float)));

@@ -42,6 +42,7 @@ SIGNATURES = {
     "itcv_conv2d_fwd_bf16s": (i32, [p, p, p, p] + [i32] * 8 + [p, sz, p]),
     "itcv_planes_bytes": (sz, [i32] * 4),
     "itcv_split_planes": (i32, [p, p, i32, i32, i32, i32, p]),
+    "itcv_conv2d_fwd_bf16p_workspace": (sz, [i32] * 7),
     "itcv_conv2d_fwd_bf16p": (i32, [p, p, p, p] + [i32] * 8 + [p, sz, p]),
     "itcv_conv2d_wgrad_bf16p_supported": (i32, [i32] * 6),
     "itcv_conv2d_wgrad_bf16p_workspace": (sz, [i32] * 6),

@@ -172,7 +172,7 @@ def conv_apply_planes(xp, weight, w4, for_dgrad, bias, B, Ci, H, W, Co, KS, up2,
     """conv_apply with the input given as pre-split planes (LDS-DMA kernel, no gather)."""
     wp = packed_weight(weight, w4, for_dgrad, ns)
     y = torch.empty((B, Co, H, W), dtype=F32, device=xp.device)
-    nws = lib.itcv_conv2d_fwd_bf16s_workspace(B, Ci, H, W, Co, KS)
+    nws = lib.itcv_conv2d_fwd_bf16p_workspace(B, Ci, H, W, Co, KS, ns)
     ws = _ws(nws, xp.device) if nws else None
 
     call("itcv_conv2d_fwd_bf16p", ptr(xp), ptr(wp), ptr(bias), ptr(y), B, Ci, H, W, Co, KS, int(up2), ns, ptr(ws), nws,
