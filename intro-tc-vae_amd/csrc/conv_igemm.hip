@@ -1454,7 +1454,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_wgrad_bf16s_kernel(WgradArgs
 // reduction index is the pixel, so in LDS the operands are "K-major"; the MFMA fragments (8 consecutive
 // pixels of one channel per lane) come out of ds_read_b64_tr_b16, the gfx950 transposing LDS read -- no
 // second copy of the activations in a pixel-major layout is ever made.
-//   block  = 128 output channels x 64 input channels x the 3 taps of one filter row (dh), one K slice
+//   block  = 128 output x 64 input channels (64 x 128 when Co <= 64) x the 3 taps of one filter row (dh), one K slice
 //   step   = 64 consecutive pixels; X arrives once per step as a halo'd band (NR rows x (W+2) columns, the
 //            rows already shifted by dh): the 3 taps read it at column offsets -1/0/+1
 //   waves  = 8 MFMA waves (4 x 2, a 32x32 tile x 3 taps each) + 4 loader waves (LDS-DMA, two stages)
@@ -1480,12 +1480,14 @@ __device__ __forceinline__ void tr_read8(bf16x8& dst, uint32_t addr0, uint32_t a
   dst = __builtin_bit_cast(bf16x8, v);
 }
 
-template <int LOG2W, bool UP2>
+template <int LOG2W, bool UP2, int BM>
 __global__ __launch_bounds__(768) void conv_wgrad_bf16p_kernel(WgradArgsP a) {
   constexpr int W = 1 << LOG2W, NR = 64 >> LOG2W, WP = W + 2, NP = NR * WP;   // band: NR rows x (W+2) columns
   constexpr int PXA = 68, PXB = ((NP + 11) / 16) * 16 + 4;                     // row strides = 4 (mod 16) chunks: conflict-free tr reads
   static_assert(PXB >= NP && PXB % 16 == 4, "band stride");
-  constexpr int ASZ = 2 * 16 * PXA, BSZ = 2 * 8 * PXB, SSZ = ASZ + BSZ;        // chunks per stage
+  constexpr int BN = 8192 / BM, ACH = BM / 8, BCH = BN / 8;                    // 128 x 64 or 64 x 128 (co x ci)
+  constexpr int WMn = BM / 32, WNn = 8 / WMn;
+  constexpr int ASZ = 2 * ACH * PXA, BSZ = 2 * BCH * PXB, SSZ = ASZ + BSZ;     // chunks per stage
   extern __shared__ u32x4 smem[];
 
   const int t = threadIdx.x, lane = t & 63;
@@ -1496,7 +1498,7 @@ __global__ __launch_bounds__(768) void conv_wgrad_bf16p_kernel(WgradArgsP a) {
   const int dhi = bid % 3;
   bid /= 3;
   const int tn = bid % a.tiles_n, tm = bid / a.tiles_n;
-  const int co0 = tm * 128, ci0 = tn * 64;
+  const int co0 = tm * BM, ci0 = tn * BN;
   const int s0 = split * a.steps_per_split, s1 = min(a.steps, s0 + a.steps_per_split);
   const int H = a.H, HW = H * W;
   const uint32_t smem_base = lds_addr(smem);
@@ -1520,11 +1522,11 @@ __global__ __launch_bounds__(768) void conv_wgrad_bf16p_kernel(WgradArgsP a) {
       {
         const int g = st * 64 + lane, b = g / HW, pix = g - b * HW;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const int qq = j * 4 + lw, pl = qq >> 4, c8 = qq & 15;
+        for (int j = 0; j < 2 * ACH / 4; ++j) {
+          const int qq = j * 4 + lw, pl = qq / ACH, c8 = qq % ACH;
           const int gc8 = (co0 >> 3) + c8;
           const u32x4* src = a.dyp + ((size_t)pl * a.dyplane + ((size_t)b * Co8 + gc8) * HW + pix);
-          lds_dma16(gc8 < Co8 ? src : zero, sbase + (uint32_t)((pl * 16 + c8) * PXA) * 16u);
+          lds_dma16(gc8 < Co8 ? src : zero, sbase + (uint32_t)((pl * ACH + c8) * PXA) * 16u);
         }
       }
       // X band: rows st*NR .. st*NR+NR-1 of the (batch x height) row index, shifted by dh; 2 pieces per (plane, chunk row)
@@ -1533,13 +1535,13 @@ __global__ __launch_bounds__(768) void conv_wgrad_bf16p_kernel(WgradArgsP a) {
         const bool valid = w_ok && (unsigned)hh < (unsigned)H;
         const int spix = UP2 ? (hh >> 1) * Ws + (w >> 1) : hh * W + w;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const int qq = (j * 4 + lw) >> 1, pl = qq >> 3, c8 = qq & 7;
+        for (int j = 0; j < 4 * BCH / 4; ++j) {
+          const int qq = (j * 4 + lw) >> 1, pl = qq / BCH, c8 = qq % BCH;
           const int gc8 = (ci0 >> 3) + c8;
           const u32x4* src = a.xp + ((size_t)pl * a.xplane + ((size_t)b * Ci8 + gc8) * HWs + spix);
           if (hp_active)
             lds_dma16((valid && gc8 < Ci8) ? src : zero,
-                      sbase + (uint32_t)(ASZ + (pl * 8 + c8) * PXB + (lw & 1) * 64) * 16u);
+                      sbase + (uint32_t)(ASZ + (pl * BCH + c8) * PXB + (lw & 1) * 64) * 16u);
         }
       }
     };
@@ -1557,7 +1559,7 @@ __global__ __launch_bounds__(768) void conv_wgrad_bf16p_kernel(WgradArgsP a) {
   }
 
   // -------------------------------------------------------------------- MFMA waves
-  const int wm = wid >> 1, wn = wid & 1;
+  const int wm = wid / WNn, wn = wid % WNn;
   const int G = lane >> 4, i16 = lane & 15, q = i16 >> 2, pp = i16 & 3, half = G >> 1, rb = G & 1;
   const int l31 = lane & 31;
   f32x16 acc[3];
@@ -1585,7 +1587,7 @@ __global__ __launch_bounds__(768) void conv_wgrad_bf16p_kernel(WgradArgsP a) {
         bf16x8 af[2];
 #pragma unroll
         for (int pl = 0; pl < 2; ++pl) {
-          const uint32_t ad = sb + aoff + (uint32_t)(pl * 16 * PXA * 16 + kk * 256);
+          const uint32_t ad = sb + aoff + (uint32_t)(pl * ACH * PXA * 16 + kk * 256);
           tr_read8(af[pl], ad, ad + 64);
         }
 #pragma unroll
@@ -1593,7 +1595,7 @@ __global__ __launch_bounds__(768) void conv_wgrad_bf16p_kernel(WgradArgsP a) {
           bf16x8 bfr[2];
 #pragma unroll
           for (int pl = 0; pl < 2; ++pl) {
-            const uint32_t bd = sb + boff + (uint32_t)(pl * 8 * PXB * 16 + (tp - 1) * 16);
+            const uint32_t bd = sb + boff + (uint32_t)(pl * BCH * PXB * 16 + (tp - 1) * 16);
             tr_read8(bfr[pl], bd + hidx16[kk * 2], bd + hidx16[kk * 2 + 1]);
           }
           f32x16 c = acc[tp];
@@ -1746,6 +1748,14 @@ static WgPlan plan_wgrad(int B, int Ci, int H, int W, int Co, int KS) {
   p.tiles = p.mt * p.nt;
   p.ktiles = (int)((Ktot + 31) / 32);
   int splits = cdiv(768, p.tiles);
+  if (p.cb == 4) {   // one 128-column tile: a block per CU with long K slices; the slab reduce shrinks with the splits
+    static int s4 = -1;
+    if (s4 < 0) {
+      const char* e = getenv("ITCV_WG4_SPLITS");
+      s4 = e ? atoi(e) : 256;
+    }
+    splits = cdiv(s4, p.tiles);
+  }
   if (splits > p.ktiles / 8) splits = p.ktiles / 8;
   if (splits > 256) splits = 256;
   if (splits < 1) splits = 1;
@@ -1981,11 +1991,12 @@ static void launch_fwd_p2_w(const ConvArgsP2& a, int bm, int up2, int splits, si
 }
 
 struct WgPlanP {
-  int tiles_m, tiles_n, steps, splits, sps;
+  int bm, tiles_m, tiles_n, steps, splits, sps;
 };
 static WgPlanP plan_wgrad_p(int B, int Ci, int H, int W, int Co) {
   WgPlanP p;
-  p.tiles_m = cdiv(Co, 128), p.tiles_n = cdiv(Ci, 64);
+  p.bm = (Co <= 64 && Ci >= 128) ? 64 : 128;    // 64 x 128 (co x ci) tiles when the output side is narrow
+  p.tiles_m = cdiv(Co, p.bm), p.tiles_n = cdiv(Ci, 8192 / p.bm);
   p.steps = (int)(((long long)B * H * W) / 64);
   const int T = p.tiles_m * p.tiles_n * 3;
   int splits = 256 / T;                       // one 768-thread block per CU
@@ -1996,26 +2007,27 @@ static WgPlanP plan_wgrad_p(int B, int Ci, int H, int W, int Co) {
   return p;
 }
 
-template <int LOG2W>
-static void launch_wgrad_p(const WgradArgsP& a, int up2, int blocks, hipStream_t st) {
+template <int LOG2W, bool UP2, int BM>
+static void launch_wgrad_p_cfg(const WgradArgsP& a, int blocks, hipStream_t st) {
   constexpr int W = 1 << LOG2W, NP = (64 >> LOG2W) * (W + 2), PXB = ((NP + 11) / 16) * 16 + 4;
-  constexpr size_t lds = (size_t)2 * (2 * 16 * 68 + 2 * 8 * PXB) * 16;
+  constexpr size_t lds = (size_t)2 * (2 * (BM / 8) * 68 + 2 * (8192 / BM / 8) * PXB) * 16;
   static_assert(lds <= 160 * 1024, "LDS");
-  static bool attr_set[2] = {false, false};
-  if (up2) {
-    auto kern = conv_wgrad_bf16p_kernel<LOG2W, true>;
-    if (!attr_set[1]) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      attr_set[1] = true;
-    }
-    hipLaunchKernelGGL(kern, dim3(blocks), dim3(768), lds, st, a);
+  auto kern = conv_wgrad_bf16p_kernel<LOG2W, UP2, BM>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(blocks), dim3(768), lds, st, a);
+}
+template <int LOG2W>
+static void launch_wgrad_p(const WgradArgsP& a, int bm, int up2, int blocks, hipStream_t st) {
+  if (bm == 64) {
+    if (up2) launch_wgrad_p_cfg<LOG2W, true, 64>(a, blocks, st);
+    else launch_wgrad_p_cfg<LOG2W, false, 64>(a, blocks, st);
   } else {
-    auto kern = conv_wgrad_bf16p_kernel<LOG2W, false>;
-    if (!attr_set[0]) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      attr_set[0] = true;
-    }
-    hipLaunchKernelGGL(kern, dim3(blocks), dim3(768), lds, st, a);
+    if (up2) launch_wgrad_p_cfg<LOG2W, true, 128>(a, blocks, st);
+    else launch_wgrad_p_cfg<LOG2W, false, 128>(a, blocks, st);
   }
 }
 
@@ -2487,13 +2499,13 @@ int itcv_conv2d_wgrad_bf16p(const void* xplanes, const void* dyplanes, float* dw
   hipStream_t st = S(stream);
   const int blocks = p.tiles_m * p.tiles_n * 3 * p.splits;
   {
-    ProfScope prof(st, 7, KS, 128, up2 ? 1 : 0, 2, 2.0 * B * H * W * (double)Co * Ci * KS * KS);
+    ProfScope prof(st, 7, KS, p.bm, up2 ? 1 : 0, 2, 2.0 * B * H * W * (double)Co * Ci * KS * KS);
     switch (log2_exact(W)) {
-      case 2: launch_wgrad_p<2>(a, up2, blocks, st); break;
-      case 3: launch_wgrad_p<3>(a, up2, blocks, st); break;
-      case 4: launch_wgrad_p<4>(a, up2, blocks, st); break;
-      case 5: launch_wgrad_p<5>(a, up2, blocks, st); break;
-      default: launch_wgrad_p<6>(a, up2, blocks, st); break;
+      case 2: launch_wgrad_p<2>(a, p.bm, up2, blocks, st); break;
+      case 3: launch_wgrad_p<3>(a, p.bm, up2, blocks, st); break;
+      case 4: launch_wgrad_p<4>(a, p.bm, up2, blocks, st); break;
+      case 5: launch_wgrad_p<5>(a, p.bm, up2, blocks, st); break;
+      default: launch_wgrad_p<6>(a, p.bm, up2, blocks, st); break;
     }
   }
   ITCV_CHECK_LAUNCH("itcv_conv2d_wgrad_bf16p");
