@@ -153,8 +153,9 @@ int itcv_bn_act_fwd(const float* x, const float* mean, const float* rstd, const 
                     float slope, int pool, void* planes, int ns, void* stream);
 /* `planes` (may be NULL): the same launch also writes the output as pre-split bf16 planes
  * [ns][B][C/8][Ho][Wo] for the consumer conv (itcv_conv2d_fwd_bf16p / _wgrad_bf16p); needs
- * itcv_bn_act_planes_supported(C, H, W, pool).  The fp32 output is bitwise unchanged.  The same holds
- * for `dx_planes` of itcv_bn_act_bwd_apply (planes of dx, pool = 0 in the support query). */
+ * itcv_bn_act_planes_supported(C, H, W, pool).  The fp32 output is bitwise unchanged; with planes given,
+ * `y` may be NULL (fp32 output not written: the consumer GEMMs read only the planes).  The same holds
+ * for `dx_planes` / `dx` of itcv_bn_act_bwd_apply (planes of dx, pool = 0 in the support query). */
 int itcv_bn_act_planes_supported(int C, int H, int W, int pool);
 /* backward, stage 1: dsums[0..C) = sum g, dsums[C..2C) = sum g*xhat where
  * g = unpool(dy) * lrelu'(bn_out (+skip)); `up2`!=0 means dy is the gradient of the x2-upsampled

@@ -224,7 +224,7 @@ __global__ void bn_act_fwd_planes_kernel(const float* __restrict__ x, const floa
           v.x += k.x, v.y += k.y, v.z += k.z, v.w += k.w;
         }
         v.x = lrelu(v.x, slope), v.y = lrelu(v.y, slope), v.z = lrelu(v.z, slope), v.w = lrelu(v.w, slope);
-        *reinterpret_cast<float4*>(y + i) = v;
+        if (y) *reinterpret_cast<float4*>(y + i) = v;
         o[j][0] = v.x, o[j][1] = v.y, o[j][POOL ? 0 : 2] = v.z, o[j][POOL ? 1 : 3] = v.w;
       } else {
         const uint32_t ho = (pp * 2) / Wo, wo = pp * 2 - ho * Wo;
@@ -241,7 +241,7 @@ __global__ void bn_act_fwd_planes_kernel(const float* __restrict__ x, const floa
         }
         const float r0 = 0.25f * (lrelu(v0, slope) + lrelu(v1, slope) + lrelu(v2, slope) + lrelu(v3, slope));
         const float r1 = 0.25f * (lrelu(w0, slope) + lrelu(w1, slope) + lrelu(w2, slope) + lrelu(w3, slope));
-        *reinterpret_cast<float2*>(y + bc * HWo + (size_t)pp * 2) = make_float2(r0, r1);
+        if (y) *reinterpret_cast<float2*>(y + bc * HWo + (size_t)pp * 2) = make_float2(r0, r1);
         o[j][0] = r0, o[j][1] = r1;
       }
     }
@@ -475,7 +475,7 @@ __global__ void bn_bwd_apply_planes(const float* __restrict__ x, const float* __
       if (!(u3 > 0.f)) g.w *= slope;
       const float4 d = make_float4(gr * (g.x - m1 - xh0 * m2), gr * (g.y - m1 - xh1 * m2), gr * (g.z - m1 - xh2 * m2),
                                    gr * (g.w - m1 - xh3 * m2));
-      *reinterpret_cast<float4*>(dx + i) = d;
+      if (dx) *reinterpret_cast<float4*>(dx + i) = d;
       if (dskip) *reinterpret_cast<float4*>(dskip + i) = g;
       o[j][0] = d.x, o[j][1] = d.y, o[j][2] = d.z, o[j][3] = d.w;
     }
@@ -662,7 +662,7 @@ int itcv_bn_act_planes_supported(int C, int H, int W, int pool) {
 int itcv_bn_act_fwd(const float* x, const float* mean, const float* rstd, const float* gamma, const float* beta,
                     const float* skip, float* y, int B, int C, int H, int W, float slope, int pool, void* planes,
                     int ns, void* stream) {
-  ITCV_REQUIRE(x && mean && rstd && gamma && beta && y && B > 0 && C > 0 && H > 0 && W > 0, "itcv_bn_act_fwd");
+  ITCV_REQUIRE(x && mean && rstd && gamma && beta && (y || planes) && B > 0 && C > 0 && H > 0 && W > 0, "itcv_bn_act_fwd");
   ITCV_REQUIRE((size_t)B * C * H * W < (1ull << 31), "itcv_bn_act_fwd(tensor < 2^31 elements)");
   if (planes) {
     ITCV_REQUIRE((ns == 2 || ns == 3) && itcv_bn_act_planes_supported(C, H, W, pool), "itcv_bn_act_fwd(planes)");
@@ -744,7 +744,7 @@ int itcv_bn_act_bwd_apply(const float* x, const float* dy, const float* mean, co
                           const float* beta, const float* skip, const double* dsums, const double* local_dsums,
                           double count, float* dx, float* dskip, float* dgamma, float* dbeta, int accumulate, int B,
                           int C, int H, int W, float slope, int pool, int up2, void* dx_planes, int ns, void* stream) {
-  ITCV_REQUIRE(x && dy && mean && rstd && gamma && beta && dsums && dx && B > 0 && C > 0 && count > 0,
+  ITCV_REQUIRE(x && dy && mean && rstd && gamma && beta && dsums && (dx || dx_planes) && B > 0 && C > 0 && count > 0,
                "itcv_bn_act_bwd_apply");
   ITCV_REQUIRE(!(pool && up2), "itcv_bn_act_bwd_apply(pool and up2 are exclusive)");
   const size_t n = (size_t)B * C * H * W;

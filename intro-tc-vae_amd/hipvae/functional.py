@@ -71,6 +71,7 @@ _CONV_MATH = [_os.environ.get("ITCV_CONV_MATH", "fp32")]
 assert _CONV_MATH[0] in _NS, "ITCV_CONV_MATH must be one of fp32 / bf16x3 / bf16x6"
 
 
+_POISON = [_os.environ.get("ITCV_POISON", "0") == "1"]   # diagnostic: fill planes-only tensors with NaN
 _PLANES = [_os.environ.get("ITCV_PLANES", "1") != "0"]   # split-bf16 convs take pre-split operands (LDS-DMA kernels)
 
 
@@ -273,9 +274,17 @@ def bias_grad_raw(dy, B, C, HW, target=None):
 PLANES_STATS = [0, 0]   # conv operands taken from producer-attached planes / split on demand (diagnostic)
 
 
-def _tag_planes(t, planes, ns):
-    """Attach the pre-split planes of ``t`` to the tensor object (consumed by the next conv GEMM)."""
-    t._itcv_planes = (planes, ns, t._version, t.data_ptr())
+def _tag_planes(t, planes, ns, fp32_valid=True):
+    """Attach the pre-split planes of ``t`` to the tensor object (consumed by the next conv GEMM).
+    ``fp32_valid=False``: the producer did not write ``t`` itself -- only the planes carry its values."""
+    t._itcv_planes = (planes, ns, t._version, t.data_ptr(), fp32_valid)
+
+
+def _require_fp32(t, what):
+    tag = getattr(t, "_itcv_planes", None)
+    if tag is not None and not tag[4]:
+        raise abi.HipExtensionError(f"{what}: this tensor was produced as planes only (fp32 values not written)")
+    return t
 
 
 def _tagged_planes(t, ns):
@@ -309,6 +318,27 @@ def conv_grad_planes_ns(conv, needs_input_grad=True):
     if not ns and _NS[_CONV_MATH[0]] == 2 and _PLANES[0] and ks == 3:
         ns = 2    # weight gradient on planes (shape support is re-checked where the planes are consumed)
     return ns
+
+
+def conv_input_mode(conv, B, H, W, up2=False):
+    """(ns, fp32_needed) for the tensor feeding ``conv`` whose OUTPUT is [B, Co, H, W]: the number of planes its
+    producer should emit, and whether the fp32 tensor itself is still read (fallback kernels)."""
+    ns = conv_input_planes_ns(conv, up2)
+    if not ns:
+        return 0, True
+    ks = conv.kernel_size[0]
+    return ns, not (ns == 2 and _wgrad_planes_ok(B, conv.in_channels, H, W, conv.out_channels, ks))
+
+
+def conv_grad_mode(conv, B, H, W, needs_input_grad=True):
+    """(ns, fp32_needed) for the gradient of ``conv``'s output [B, Co, H, W]."""
+    ns = conv_grad_planes_ns(conv, needs_input_grad)
+    if not ns:
+        return 0, True
+    ks = conv.kernel_size[0]
+    dgrad_ok = (not needs_input_grad) or _planes_ns(conv.out_channels, conv.in_channels, ks, False) == ns
+    wgrad_ok = ns == 2 and _wgrad_planes_ok(B, conv.in_channels, H, W, conv.out_channels, ks)
+    return ns, not (dgrad_ok and wgrad_ok and conv.bias is None)
 
 
 def _planes_ns(Ci, Co, KS, up2):
@@ -345,10 +375,11 @@ class Conv2dFn(Function):
             xp = planes_of(x, ns)
             y = conv_apply_planes(xp, weight, weight, 0, b, B, Ci, H, W, Co, KS, up2, ns)
         else:
-            y = conv_apply(x, weight, weight, 0, b, B, Ci, H, W, Co, KS, up2)
+            y = conv_apply(_require_fp32(x, "Conv2dFn.forward"), weight, weight, 0, b, B, Ci, H, W, Co, KS, up2)
         wg_planes = _wgrad_planes_ok(B, Ci, H, W, Co, KS)
         keep_xp = xp if (wg_planes and ns == 2) else None
-        ctx.save_for_backward(None if keep_xp is not None else x, weight, bias, keep_xp)
+        ctx.save_for_backward(None if keep_xp is not None else _require_fp32(x, "Conv2dFn.forward (saved input)"),
+                              weight, bias, keep_xp)
         ctx.cfg = (B, Ci, H, W, Co, KS, up2, bias is not None, (Hs, Ws))
         return y
 
@@ -368,7 +399,7 @@ class Conv2dFn(Function):
             if ns_d:
                 dx = conv_apply_planes(dyp, weight, weight, 1, None, B, Co, H, W, Ci, KS, False, ns_d)
             else:
-                dx = conv_apply(dy, weight, weight, 1, None, B, Co, H, W, Ci, KS, False)
+                dx = conv_apply(_require_fp32(dy, "Conv2dFn.backward"), weight, weight, 1, None, B, Co, H, W, Ci, KS, False)
             if up2:
                 lo = torch.empty((B, Ci, H // 2, W // 2), dtype=F32, device=dy.device)
                 call("itcv_upsample2_bwd", ptr(dx), ptr(lo), B * Ci, H // 2, W // 2, stream())
@@ -385,12 +416,13 @@ class Conv2dFn(Function):
             else:
                 if x is None:
                     raise abi.HipExtensionError("Conv2dFn.backward: conv math mode changed between forward and backward")
+                _require_fp32(dy, "Conv2dFn.backward (weight gradient)")
                 if tgt is not None:
                     conv_wgrad_raw(x, dy, B, Ci, H, W, Co, KS, up2, out=tgt, accumulate=True)
                 else:
                     dw = conv_wgrad_raw(x, dy, B, Ci, H, W, Co, KS, up2)
         if has_bias and ctx.needs_input_grad[2]:
-            db = bias_grad_raw(dy, B, Co, H * W, _grad_target(bias))
+            db = bias_grad_raw(_require_fp32(dy, "Conv2dFn.backward (bias gradient)"), B, Co, H * W, _grad_target(bias))
         return dx, dw, db, None
 
 
@@ -439,7 +471,7 @@ class BnActFn(Function):
 
     @staticmethod
     def forward(ctx, x, gamma, beta, skip, running_mean, running_var, nbt, eps, momentum, slope, pool, training,
-                group, out_planes=0, grad_planes=0):
+                group, out_planes=0, grad_planes=0, out_fp32=True, grad_fp32=True):
         x, gamma, beta = _f32c(x), _f32c(gamma), _f32c(beta)
         skip = None if skip is None else _f32c(skip)
         B, C, H, W = x.shape
@@ -468,15 +500,19 @@ class BnActFn(Function):
         if out_planes and lib.itcv_bn_act_planes_supported(C, H, W, int(pool)):
             yp = torch.empty(lib.itcv_planes_bytes(B, C, oshape[2] * oshape[3], out_planes) // 4, dtype=torch.int32,
                              device=dev)
-        call("itcv_bn_act_fwd", ptr(x), ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), ptr(skip), ptr(y), B, C, H, W,
-             float(slope), int(pool), ptr(yp), int(out_planes), stream())
+        write_y = out_fp32 or yp is None or _POISON[0]
+        call("itcv_bn_act_fwd", ptr(x), ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), ptr(skip),
+             ptr(y) if write_y else None, B, C, H, W, float(slope), int(pool), ptr(yp), int(out_planes), stream())
         if yp is not None:
-            _tag_planes(y, yp, out_planes)
+            if _POISON[0] and not out_fp32:
+                y.fill_(float("nan"))
+            _tag_planes(y, yp, out_planes, bool(out_fp32))
         ctx.save_for_backward(x, gamma, beta, mean, rstd, skip)
         ctx.params = (gamma, beta)
         if not lib.itcv_bn_act_planes_supported(C, H, W, 0):
             grad_planes = 0
-        ctx.cfg = (B, C, H, W, float(slope), int(pool), bool(training), group, world, int(grad_planes))
+        ctx.cfg = (B, C, H, W, float(slope), int(pool), bool(training), group, world, int(grad_planes),
+                   bool(grad_fp32) or not grad_planes)
         ctx.mark_non_differentiable(*[t for t in (running_mean, running_var, nbt) if t is not None])
         return y
 
@@ -484,7 +520,7 @@ class BnActFn(Function):
     @once_differentiable
     def backward(ctx, dy):
         x, gamma, beta, mean, rstd, skip = ctx.saved_tensors
-        B, C, H, W, slope, pool, training, group, world, grad_planes = ctx.cfg
+        B, C, H, W, slope, pool, training, group, world, grad_planes, grad_fp32 = ctx.cfg
         if not training:
             raise abi.HipExtensionError("BatchNorm backward in eval mode is not part of the training hot path")
         dy = _f32c(dy)
@@ -515,12 +551,15 @@ class BnActFn(Function):
         dxp = None
         if grad_planes:
             dxp = torch.empty(lib.itcv_planes_bytes(B, C, H * W, grad_planes) // 4, dtype=torch.int32, device=dev)
+        write_dx = grad_fp32 or dxp is None or _POISON[0]
         call("itcv_bn_act_bwd_apply", ptr(x), ptr(dy), ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), ptr(skip),
-             ptr(total), None, float(B * H * W * world), ptr(dx), ptr(dskip), None, None, 0, B, C, H,
-             W, slope, pool, 0, ptr(dxp), grad_planes, stream())
+             ptr(total), None, float(B * H * W * world), ptr(dx) if write_dx else None, ptr(dskip), None, None, 0, B,
+             C, H, W, slope, pool, 0, ptr(dxp), grad_planes, stream())
         if dxp is not None:
-            _tag_planes(dx, dxp, grad_planes)
-        return (dx, dgamma, dbeta, dskip) + (None,) * 11
+            if _POISON[0] and not grad_fp32:
+                dx.fill_(float("nan"))
+            _tag_planes(dx, dxp, grad_planes, bool(grad_fp32))
+        return (dx, dgamma, dbeta, dskip) + (None,) * 13
 
 
 # ------------------------------------------------------------------ pointwise / resampling

@@ -44,12 +44,14 @@ class HipBatchNorm2d(nn.BatchNorm2d):
 
     sync_group = None
 
-    def forward(self, x, slope=1.0, pool=False, skip=None, out_planes=0, grad_planes=0):
-        """``out_planes`` / ``grad_planes``: number of bf16 planes in which the output / the input gradient are
-        additionally written for the neighbouring conv GEMMs (0 = not at all); see hipvae.functional."""
+    def forward(self, x, slope=1.0, pool=False, skip=None, out_mode=(0, True), grad_mode=(0, True)):
+        """``out_mode`` / ``grad_mode`` = (planes, fp32): number of bf16 planes in which the output / the input
+        gradient are additionally written for the neighbouring conv GEMMs (0 = none), and whether the fp32
+        tensor itself is still needed (False: only the planes are written); see hipvae.functional."""
         return HF.BnActFn.apply(x, self.weight, self.bias, skip, self.running_mean, self.running_var,
                                 self.num_batches_tracked, self.eps, self.momentum, slope, bool(pool), self.training,
-                                self.sync_group, int(out_planes), int(grad_planes))
+                                self.sync_group, int(out_mode[0]), int(grad_mode[0]), bool(out_mode[1]),
+                                bool(grad_mode[1]))
 
 
 class HipLeakyReLU(nn.LeakyReLU):
@@ -101,11 +103,15 @@ class ConvolutionalBlock(nn.Module):
 
     def forward(self, x, pool=False, up2=False, consumer=None, consumer_up2=False):
         """``consumer``: the conv module that reads this block's output (its planes are emitted by bn2)."""
-        y = self.bn1(self.conv1(x, up2=up2), slope=LRELU_SLOPE, out_planes=HF.conv_input_planes_ns(self.conv2),
-                     grad_planes=HF.conv_grad_planes_ns(self.conv1, x.requires_grad))
+        B, H, W = x.size(0), x.size(2) * (2 if up2 else 1), x.size(3) * (2 if up2 else 1)
+        y = self.bn1(self.conv1(x, up2=up2), slope=LRELU_SLOPE, out_mode=HF.conv_input_mode(self.conv2, B, H, W),
+                     grad_mode=HF.conv_grad_mode(self.conv1, B, H, W, x.requires_grad))
+        Hc, Wc = (H // 2, W // 2) if pool else (H, W)
+        if consumer_up2:
+            Hc, Wc = Hc * 2, Wc * 2
         return self.bn2(self.conv2(y), slope=LRELU_SLOPE, pool=pool,
-                        out_planes=HF.conv_input_planes_ns(consumer, consumer_up2),
-                        grad_planes=HF.conv_grad_planes_ns(self.conv2))
+                        out_mode=HF.conv_input_mode(consumer, B, Hc, Wc, consumer_up2) if consumer is not None else (0, True),
+                        grad_mode=HF.conv_grad_mode(self.conv2, B, H, W))
 
 
 class ResidualBlock(nn.Module):
@@ -129,11 +135,13 @@ class ResidualBlock(nn.Module):
             skip = self.conv_expand(x, up2=up2)
         else:
             skip = HF.Upsample2Fn.apply(x) if up2 else x
-        y = self.bn1(self.conv1(x, up2=up2), slope=LRELU_SLOPE, out_planes=HF.conv_input_planes_ns(self.conv2),
-                     grad_planes=HF.conv_grad_planes_ns(self.conv1, x.requires_grad))
+        # the block output also feeds the next block's skip path and x feeds this one's: fp32 stays everywhere
+        y = self.bn1(self.conv1(x, up2=up2), slope=LRELU_SLOPE,
+                     out_mode=(HF.conv_input_planes_ns(self.conv2), True),
+                     grad_mode=(HF.conv_grad_planes_ns(self.conv1, x.requires_grad), True))
         return self.bn2(self.conv2(y), slope=LRELU_SLOPE, pool=pool, skip=skip,
-                        out_planes=HF.conv_input_planes_ns(consumer, consumer_up2),
-                        grad_planes=HF.conv_grad_planes_ns(self.conv2))
+                        out_mode=(HF.conv_input_planes_ns(consumer, consumer_up2), True),
+                        grad_mode=(HF.conv_grad_planes_ns(self.conv2), True))
 
 
 class Conv2dBatchNorm(nn.Module):
@@ -236,9 +244,11 @@ class Encoder(nn.Module):
     def forward(self, x):
         if self.fused:
             blocks = [getattr(self.main, name) for name, _ in self._stages]
+            res_block = isinstance(blocks[0], ResidualBlock)    # its skip path reads the fp32 tensor
+            mode = HF.conv_input_mode(blocks[0].conv1, x.size(0), x.size(2) // 2, x.size(3) // 2)
             y = self.main[1](self.main[0](x), slope=LRELU_SLOPE, pool=True,
-                             out_planes=HF.conv_input_planes_ns(blocks[0].conv1),
-                             grad_planes=HF.conv_grad_planes_ns(self.main[0], x.requires_grad))
+                             out_mode=(mode[0], True) if res_block else mode,
+                             grad_mode=(HF.conv_grad_planes_ns(self.main[0], x.requires_grad), True))
             for k, (name, pooled) in enumerate(self._stages):
                 nxt = blocks[k + 1].conv1 if k + 1 < len(blocks) else None
                 y = blocks[k](y, pool=pooled, consumer=nxt)
