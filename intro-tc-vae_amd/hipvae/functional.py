@@ -8,6 +8,7 @@ into Sync-BN (all-reduce of the fp64 channel moments over RCCL) for data-paralle
 with the full-batch reference.
 """
 import contextlib
+import os as _os
 import weakref
 
 import torch
@@ -51,6 +52,43 @@ def direct_grad_accumulation():
 def _grad_target(param):
     g = param.grad if _DIRECT[0] else None
     return g if (g is not None and g.is_contiguous() and g.dtype == F32) else None
+
+
+# ------------------------------------------------------------------ side stream for weight gradients
+# A step is ~1700 launches, many of them a few microseconds of work that leave the chip idle.  In
+# direct-accumulation mode the weight-gradient GEMMs (+ their slab reduces) depend only on the operand
+# planes, not on the activation-gradient chain, so they run on a second HIP stream and fill those gaps;
+# under stream capture this becomes a fork/join branch of the step's hipGraph.  side_join() makes the
+# current stream wait for them (called by the solvers right after loss.backward()).
+_SIDE = {"enabled": _os.environ.get("ITCV_WGRAD_STREAM", "1") != "0", "stream": None, "dirty": False}
+
+
+def set_wgrad_stream(flag):
+    _SIDE["enabled"] = bool(flag)
+
+
+@contextlib.contextmanager
+def _on_side_stream(device, keep):
+    """Run the block on the side stream, ordered after everything issued so far on the current stream;
+    ``keep``: tensors allocated on the current stream that the block reads (their memory must outlive it)."""
+    main = torch.cuda.current_stream(device)
+    side = _SIDE["stream"]
+    if side is None or side.device != device:
+        side = _SIDE["stream"] = torch.cuda.Stream(device=device)
+    side.wait_stream(main)
+    with torch.cuda.stream(side):
+        yield
+    for t in keep:
+        if t is not None:
+            t.record_stream(side)
+    _SIDE["dirty"] = True
+
+
+def side_join():
+    """Order the current stream after all weight-gradient work issued on the side stream."""
+    if _SIDE["dirty"]:
+        torch.cuda.current_stream().wait_stream(_SIDE["stream"])
+        _SIDE["dirty"] = False
 
 
 # ------------------------------------------------------------------ convolution / linear
@@ -409,7 +447,10 @@ class Conv2dFn(Function):
             if wg_planes and (ns_d in (0, 2)):
                 if xp is None:
                     xp = split_planes(x, 2)
-                if tgt is not None:
+                if tgt is not None and _SIDE["enabled"]:
+                    with _on_side_stream(dy.device, (xp, dyp)):
+                        conv_wgrad_planes(xp, dyp, B, Ci, H, W, Co, KS, up2, out=tgt, accumulate=True)
+                elif tgt is not None:
                     conv_wgrad_planes(xp, dyp, B, Ci, H, W, Co, KS, up2, out=tgt, accumulate=True)
                 else:
                     dw = conv_wgrad_planes(xp, dyp, B, Ci, H, W, Co, KS, up2)
@@ -417,7 +458,10 @@ class Conv2dFn(Function):
                 if x is None:
                     raise abi.HipExtensionError("Conv2dFn.backward: conv math mode changed between forward and backward")
                 _require_fp32(dy, "Conv2dFn.backward (weight gradient)")
-                if tgt is not None:
+                if tgt is not None and _SIDE["enabled"]:
+                    with _on_side_stream(dy.device, (x, dy)):
+                        conv_wgrad_raw(x, dy, B, Ci, H, W, Co, KS, up2, out=tgt, accumulate=True)
+                elif tgt is not None:
                     conv_wgrad_raw(x, dy, B, Ci, H, W, Co, KS, up2, out=tgt, accumulate=True)
                 else:
                     dw = conv_wgrad_raw(x, dy, B, Ci, H, W, Co, KS, up2)
