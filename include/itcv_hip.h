@@ -93,6 +93,16 @@ int itcv_conv2d_wgrad_bf16p_supported(int B, int Ci, int H, int W, int Co, int K
 size_t itcv_conv2d_wgrad_bf16p_workspace(int B, int Ci, int H, int W, int Co, int KS);
 int itcv_conv2d_wgrad_bf16p(const void* xplanes, const void* dyplanes, float* dw, int B, int Ci, int H, int W,
                             int Co, int KS, int up2, int accumulate, void* ws, size_t ws_bytes, void* stream);
+/* nn.Linear(K -> N) at batch B (models.py:233,270) as skinny exact-fp32 MFMA GEMMs, in every conv-math mode:
+ * y[B][N] = x[B][K] w[N][K]^T + bias;  dx[B][K] = dy[B][N] w;  dw[N][K] (+)= dy^T x.  Deterministic
+ * split-K; itcv_linear_workspace serves all three. */
+size_t itcv_linear_workspace(int B, int K, int N);
+int itcv_linear_fwd(const float* x, const float* w, const float* bias, float* y, int B, int K, int N, void* ws,
+                    size_t ws_bytes, void* stream);
+int itcv_linear_dgrad(const float* dy, const float* w, float* dx, int B, int K, int N, void* ws, size_t ws_bytes,
+                      void* stream);
+int itcv_linear_wgrad(const float* dy, const float* x, float* dw, int B, int K, int N, int accumulate, void* ws,
+                      size_t ws_bytes, void* stream);
 /* Direct (vector-ALU, exact fp32) convolution for layers with at most 4 output channels -- the 5x5
  * predict conv 64->3 (models.py:290) and the data-gradient of the 5x5 stem (models.py:213), where a
  * 32-row MFMA tile would be >90 % padding.  for_dgrad = 0: w is [Co][C][KS][KS]; for_dgrad = 1: w is the

@@ -226,6 +226,103 @@ __global__ void splitk_reduce_fwd(const float* __restrict__ slab, const float* _
   }
 }
 
+// ------------------------------------------------------------------ small dense GEMMs (nn.Linear)
+// The fc layers (models.py:233,270: 8192 <-> 2*zdim / zdim <-> 8192 at batch 64) are skinny GEMMs whose cost is
+// reading the weight once.  C[M][N] = sum_k A(m,k) * B(k,n) with arbitrary element strides covers forward (x W^T),
+// data-gradient (dy W) and weight-gradient (dy^T x); exact fp32 MFMA in every conv-math mode; 64x64 tiles, split-K
+// over blockIdx.y into fp32 slabs (fixed-order reduce) when there are few tiles.
+struct GemmArgs {
+  const float* A;
+  const float* B;
+  const float* bias;   // indexed by n; only applied when the kernel writes C itself (no split-K)
+  float* C;
+  int M, N, K;
+  long long sam, sak, sbk, sbn;
+  int mt, nt, ktiles, ktiles_per_split;
+  size_t slab_stride;
+  int accumulate;
+};
+
+template <bool A_KC, bool B_KC>   // is the operand's k index the contiguous one in memory?
+__global__ __launch_bounds__(256) void gemm64_kernel(GemmArgs a) {
+  constexpr int BM = 64, BN = 64, BK = 32, PA = BM + 1, PB = BN + 1;
+  __shared__ float As[2][BK * PA];
+  __shared__ float Bs[2][BK * PB];
+  const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
+  const int wm = wid >> 1, wn = wid & 1, l31 = lane & 31, half = lane >> 5;
+  const int tile_m = blockIdx.x % a.mt, tile_n = blockIdx.x / a.mt, sk = blockIdx.y;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int kt0 = sk * a.ktiles_per_split, kt1 = min(a.ktiles, kt0 + a.ktiles_per_split);
+
+  float areg[8], breg[8];
+  auto load_tile = [&](int kt) {
+    const int kb = kt * BK;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int k = A_KC ? (t & 31) : (t >> 6) + 4 * i, m = A_KC ? (t >> 5) + 8 * i : (t & 63);
+      areg[i] = (m0 + m < a.M && kb + k < a.K) ? a.A[(long long)(m0 + m) * a.sam + (long long)(kb + k) * a.sak] : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int k = B_KC ? (t & 31) : (t >> 6) + 4 * i, n = B_KC ? (t >> 5) + 8 * i : (t & 63);
+      breg[i] = (n0 + n < a.N && kb + k < a.K) ? a.B[(long long)(kb + k) * a.sbk + (long long)(n0 + n) * a.sbn] : 0.f;
+    }
+  };
+  auto store_tile = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int k = A_KC ? (t & 31) : (t >> 6) + 4 * i, m = A_KC ? (t >> 5) + 8 * i : (t & 63);
+      As[buf][k * PA + m] = areg[i];
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int k = B_KC ? (t & 31) : (t >> 6) + 4 * i, n = B_KC ? (t >> 5) + 8 * i : (t & 63);
+      Bs[buf][k * PB + n] = breg[i];
+    }
+  };
+  f32x16 acc[1][1];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[0][0][r] = 0.f;
+  if (kt0 < kt1) {
+    load_tile(kt0);
+    store_tile(0);
+    __syncthreads();
+    int cur = 0;
+    for (int kt = kt0; kt < kt1; ++kt) {
+      const bool more = kt + 1 < kt1;
+      if (more) load_tile(kt + 1);
+      mfma_tile<BK, PA, PB, 1, 1>(&As[cur][half * PA + wm * 32 + l31], &Bs[cur][half * PB + wn * 32 + l31], acc);
+      if (more) store_tile(cur ^ 1);
+      __syncthreads();
+      cur ^= 1;
+    }
+  }
+  const int n = n0 + wn * 32 + l31;
+  if (n >= a.N) return;
+  float* out = a.C + (size_t)sk * a.slab_stride;
+  const float bv = (a.bias && !a.slab_stride) ? a.bias[n] : 0.f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+    if (m < a.M) {
+      float* q = out + (size_t)m * a.N + n;
+      const float v = acc[0][0][r] + bv;
+      *q = a.accumulate ? *q + v : v;
+    }
+  }
+}
+
+// C (+)= bias[n] + sum_s slab[s]
+__global__ void gemm64_reduce(const float* __restrict__ slab, const float* __restrict__ bias, float* __restrict__ C,
+                              size_t total, int N, int splits, int accumulate) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    float s = 0.f;
+    for (int k = 0; k < splits; ++k) s += slab[(size_t)k * total + i];
+    if (bias) s += bias[i % N];
+    C[i] = accumulate ? C[i] + s : s;
+  }
+}
+
 // wp[k][m] with k = ((c/16)*KK + tap)*16 + c%16 (16-channel block outer, tap inner); for_dgrad swaps the
 // channel roles and flips the taps
 __global__ void pack_weight_kernel(const float* __restrict__ w, float* __restrict__ wp, int Co, int Ci, int KK,
@@ -2514,6 +2611,90 @@ int itcv_conv2d_wgrad_bf16p(const void* xplanes, const void* dyplanes, float* dw
                      static_cast<const float*>(ws), dw, coci, p.splits, accumulate);
   ITCV_CHECK_LAUNCH("itcv_conv2d_wgrad_bf16p(reduce)");
   return 0;
+}
+
+// ---- nn.Linear as skinny fp32 GEMMs ----------------------------------------------------------------
+}  // extern "C"
+
+namespace itcv {
+struct GemmPlan {
+  int mt, nt, ktiles, splits, kps;
+};
+static GemmPlan plan_gemm64(int M, int N, int K) {
+  GemmPlan p;
+  p.mt = cdiv(M, 64), p.nt = cdiv(N, 64), p.ktiles = cdiv(K, 32);
+  const int tiles = p.mt * p.nt;
+  int splits = 1;
+  if (tiles < 128 && p.ktiles >= 4) {
+    splits = cdiv(256, tiles);
+    if (splits > p.ktiles / 2) splits = p.ktiles / 2;
+    if (splits < 1) splits = 1;
+  }
+  p.kps = cdiv(p.ktiles, splits);
+  p.splits = cdiv(p.ktiles, p.kps);
+  return p;
+}
+static size_t gemm64_ws(int M, int N, int K) {
+  const GemmPlan p = plan_gemm64(M, N, K);
+  return p.splits > 1 ? (size_t)p.splits * M * N * sizeof(float) : 0;
+}
+static int run_gemm64(const char* name, const float* A, const float* B, const float* bias, float* C, int M, int N,
+                      int K, long long sam, long long sak, long long sbk, long long sbn, int accumulate, void* ws,
+                      size_t ws_bytes, hipStream_t st) {
+  const GemmPlan p = plan_gemm64(M, N, K);
+  const size_t need = p.splits > 1 ? (size_t)p.splits * M * N * sizeof(float) : 0;
+  if (need && (!ws || ws_bytes < need)) return fail("%s: workspace too small (need %lld bytes)", name, (long long)need);
+  GemmArgs a;
+  a.A = A, a.B = B, a.bias = bias;
+  a.C = p.splits > 1 ? static_cast<float*>(ws) : C;
+  a.M = M, a.N = N, a.K = K;
+  a.sam = sam, a.sak = sak, a.sbk = sbk, a.sbn = sbn;
+  a.mt = p.mt, a.nt = p.nt, a.ktiles = p.ktiles, a.ktiles_per_split = p.kps;
+  a.slab_stride = p.splits > 1 ? (size_t)M * N : 0;
+  a.accumulate = p.splits > 1 ? 0 : accumulate;
+  dim3 grid(p.mt * p.nt, p.splits), blk(256);
+  const bool akc = sak == 1, bkc = sbk == 1;
+  if (akc && bkc) hipLaunchKernelGGL((gemm64_kernel<true, true>), grid, blk, 0, st, a);
+  else if (akc) hipLaunchKernelGGL((gemm64_kernel<true, false>), grid, blk, 0, st, a);
+  else if (bkc) hipLaunchKernelGGL((gemm64_kernel<false, true>), grid, blk, 0, st, a);
+  else hipLaunchKernelGGL((gemm64_kernel<false, false>), grid, blk, 0, st, a);
+  ITCV_CHECK_LAUNCH(name);
+  if (p.splits > 1) {
+    const size_t total = (size_t)M * N;
+    hipLaunchKernelGGL(gemm64_reduce, dim3((int)(cdivz(total, 256) < 1024 ? cdivz(total, 256) : 1024)), dim3(256), 0, st,
+                       static_cast<const float*>(ws), bias, C, total, N, p.splits, accumulate);
+    ITCV_CHECK_LAUNCH(name);
+  }
+  return 0;
+}
+}  // namespace itcv
+
+extern "C" {
+
+// nn.Linear(K -> N) at batch B: y[B][N] = x[B][K] w[N][K]^T + bias; dx[B][K] = dy[B][N] w; dw[N][K] (+)= dy^T x.
+// One workspace size serves all three.
+size_t itcv_linear_workspace(int B, int K, int N) {
+  if (B <= 0 || K <= 0 || N <= 0) return 0;
+  size_t n = gemm64_ws(B, N, K);
+  const size_t d = gemm64_ws(B, K, N), w = gemm64_ws(N, K, B);
+  if (d > n) n = d;
+  if (w > n) n = w;
+  return n;
+}
+int itcv_linear_fwd(const float* x, const float* w, const float* bias, float* y, int B, int K, int N, void* ws,
+                    size_t ws_bytes, void* stream) {
+  ITCV_REQUIRE(x && w && y && B > 0 && K > 0 && N > 0, "itcv_linear_fwd");
+  return run_gemm64("itcv_linear_fwd", x, w, bias, y, B, N, K, K, 1, 1, K, 0, ws, ws_bytes, S(stream));
+}
+int itcv_linear_dgrad(const float* dy, const float* w, float* dx, int B, int K, int N, void* ws, size_t ws_bytes,
+                      void* stream) {
+  ITCV_REQUIRE(dy && w && dx && B > 0 && K > 0 && N > 0, "itcv_linear_dgrad");
+  return run_gemm64("itcv_linear_dgrad", dy, w, nullptr, dx, B, K, N, N, 1, K, 1, 0, ws, ws_bytes, S(stream));
+}
+int itcv_linear_wgrad(const float* dy, const float* x, float* dw, int B, int K, int N, int accumulate, void* ws,
+                      size_t ws_bytes, void* stream) {
+  ITCV_REQUIRE(dy && x && dw && B > 0 && K > 0 && N > 0, "itcv_linear_wgrad");
+  return run_gemm64("itcv_linear_wgrad", dy, x, nullptr, dw, N, K, B, 1, N, K, 1, accumulate, ws, ws_bytes, S(stream));
 }
 
 // Which kernel instantiation / decomposition a call resolves to (for profiling buckets):

@@ -471,36 +471,42 @@ class Conv2dFn(Function):
 
 
 class LinearFn(Function):
-    """nn.Linear as the KS=1, H=W=1 case of the implicit-GEMM kernel."""
+    """nn.Linear on the skinny fp32 MFMA GEMMs (itcv_linear_*): exact fp32 in every conv-math mode."""
 
     @staticmethod
     def forward(ctx, x, weight, bias):
         x, weight = _f32c(x), _f32c(weight)
-        B, Ci = x.shape
-        Co = weight.shape[0]
-        w4 = weight.view(Co, Ci, 1, 1)
-        y = conv_apply(x, weight, w4, 0, None if bias is None else _f32c(bias), B, Ci, 1, 1, Co, 1, False)
+        B, K = x.shape
+        N = weight.shape[0]
+        y = torch.empty((B, N), dtype=F32, device=x.device)
+        nws = lib.itcv_linear_workspace(B, K, N)
+        ws = _ws(nws, x.device) if nws else None
+        call("itcv_linear_fwd", ptr(x), ptr(weight), ptr(None if bias is None else _f32c(bias)), ptr(y), B, K, N, ptr(ws),
+             nws, stream())
         ctx.save_for_backward(x, weight, bias)
-        ctx.cfg = (B, Ci, Co, bias is not None)
-        return y.view(B, Co)
+        ctx.cfg = (B, K, N, bias is not None)
+        return y
 
     @staticmethod
     @once_differentiable
     def backward(ctx, dy):
         x, weight, bias = ctx.saved_tensors
-        B, Ci, Co, has_bias = ctx.cfg
+        B, K, N, has_bias = ctx.cfg
         dy = _f32c(dy)
         dx = dw = db = None
+        nws = lib.itcv_linear_workspace(B, K, N)
         if ctx.needs_input_grad[0]:
-            dx = conv_apply(dy, weight, weight.view(Co, Ci, 1, 1), 1, None, B, Co, 1, 1, Ci, 1, False).view(B, Ci)
+            dx = torch.empty((B, K), dtype=F32, device=dy.device)
+            ws = _ws(nws, dy.device) if nws else None
+            call("itcv_linear_dgrad", ptr(dy), ptr(weight), ptr(dx), B, K, N, ptr(ws), nws, stream())
         if ctx.needs_input_grad[1]:
             tgt = _grad_target(weight)
-            if tgt is not None:
-                conv_wgrad_raw(x, dy, B, Ci, 1, 1, Co, 1, False, out=tgt, accumulate=True)
-            else:
-                dw = conv_wgrad_raw(x, dy, B, Ci, 1, 1, Co, 1, False).view(Co, Ci)
+            dw = None if tgt is not None else torch.empty((N, K), dtype=F32, device=dy.device)
+            ws = _ws(nws, dy.device) if nws else None
+            call("itcv_linear_wgrad", ptr(dy), ptr(x), ptr(tgt if tgt is not None else dw), B, K, N,
+                 int(tgt is not None), ptr(ws), nws, stream())
         if has_bias and ctx.needs_input_grad[2]:
-            db = bias_grad_raw(dy, B, Co, 1, _grad_target(bias))
+            db = bias_grad_raw(dy, B, N, 1, _grad_target(bias))
         return dx, dw, db
 
 

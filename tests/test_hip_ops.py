@@ -124,12 +124,15 @@ def test_conv_full_size_layer(HF):
     assert rel_err(wd.grad, wr.grad) < 5e-5     # K = 262144-term sums in fp32 slabs
 
 
-def test_linear(HF):
-    g = torch.Generator().manual_seed(3)
-    x = torch.randn(64, 512, generator=g)
-    w = torch.randn(40, 512, generator=g) / 22
-    b = torch.randn(40, generator=g)
-    dy = torch.randn(64, 40, generator=g)
+@pytest.mark.parametrize("shape", [(64, 512, 40), (5, 96, 70), (64, 8192, 256), (64, 128, 8192), (3, 33, 130)])
+def test_linear(HF, shape):
+    """nn.Linear on the skinny fp32 GEMMs: ragged tiles, both fc shapes of the c2 model (split-K and not)."""
+    B, K, N = shape
+    g = torch.Generator().manual_seed(3 + B + N)
+    x = torch.randn(B, K, generator=g)
+    w = torch.randn(N, K, generator=g) / K ** 0.5
+    b = torch.randn(N, generator=g)
+    dy = torch.randn(B, N, generator=g)
     xr, wr, br = (t.double().requires_grad_(True) for t in (x, w, b))
     F.linear(xr, wr, br).backward(dy.double())
     xd, wd, bd = (t.to(dev()).requires_grad_(True) for t in (x, w, b))
