@@ -2627,6 +2627,7 @@ static GemmPlan plan_gemm64(int M, int N, int K) {
   int splits = 1;
   if (tiles < 128 && p.ktiles >= 4) {
     splits = cdiv(256, tiles);
+    if (splits > 32) splits = 32;             // the slab reduce is a serial chain over the splits
     if (splits > p.ktiles / 2) splits = p.ktiles / 2;
     if (splits < 1) splits = 1;
   }
