@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Headline benchmark: images/sec of one IntroTCSovler.train_step (Soft-Intro beta-TC-VAE step:
 5 encoder + 8 decoder forwards, 2 backwards, 2 Adam updates) on synthetic 64x64x3 batches,
-z_dim=128, batch 64 per GPU, conv architecture -- BASELINE.json configs[1] (c2), fp32.
+z_dim=128, batch 64 per GPU, conv architecture -- BASELINE.json configs[1] (c2).  fp32 tensors; the conv
+products run in the mode --math selects (default bf16x3 = what the reference's use_amp=True config maps to).
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
@@ -14,9 +15,9 @@ the timed region; the timed region is bracketed by barrier + synchronize on both
 maximum over ranks is reported.
 
 Extra objects on the line:
-  roofline      dominant kernel (implicit-GEMM conv on the fp32 matrix cores): algorithmic FLOP of
-                its launches / their HIP-event durations, measured live during the timed steps on
-                the launch stream; peak = 157.3 TFLOP/s dense fp32 MFMA (MI355X_MICROARCH.md).
+  roofline      dominant kernel (an implicit-GEMM conv on the matrix cores): algorithmic FLOP of its
+                launches / their HIP-event durations, measured live on the launch stream; peak = dense
+                MFMA peak of the arithmetic (2500/3 TFLOP/s for bf16x3, 157.3 for fp32; MI355X_MICROARCH.md).
   cpu_baseline  the CPU oracle (oracle/, a PyTorch-CPU port pinned to the reference by golden
                 vectors) timed on the host cores on a bounded sample of the same workload.
 """
@@ -205,19 +206,14 @@ def main():
     else:
         peak, peak_note = PEAK_F32_MFMA_TFLOPS, "dense fp32 MFMA"
     traffic, traffic_note = None, None
-    try:   # HBM bytes per launch from the committed rocprofv3 --pmc passes over this same command
+    try:   # HBM bytes per launch from the committed rocprofv3 --pmc passes over this same command (tools/pmc_summary.py)
         pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
-        fam = dom_label.split("<")[0]
-        args_ = dom_label[dom_label.index("<") + 1:-1].split(",")
-        want = [a.split("=")[1] for a in args_]
-        for name, rec in pmc["kernels"].items():
-            if fam + "<" in name and args.math == "bf16x3":
-                targs = name[name.index("<") + 1:name.index(">")].replace(" ", "").split(",")
-                # template order: KS, BM, BN, WM, WN, UP2, NS  vs label KS, BM, up2, NS
-                if targs[0] == want[0] and targs[1] == want[1] and targs[-1] == want[-1] and targs[-2] == ("true" if want[2] == "1" else "false"):
-                    traffic = rec["hbm_bytes_per_launch_fetch_x2"]
-                    traffic_note = ("profiles/r01_pmc_traffic.json: (2*FETCH_SIZE + WRITE_SIZE)*1024 per launch, rocprofv3 --pmc, "
-                                    f"separate passes; raw (uncorrected) = {rec['hbm_bytes_per_launch_raw']}")
+        rec = pmc["kernels"].get(dom_label) if args.math == pmc.get("math") else None
+        if rec:
+            traffic = rec["hbm_bytes_per_launch_fetch_x2"]
+            traffic_note = ("profiles/r01_pmc_traffic.json: (2*FETCH_SIZE + WRITE_SIZE)*1024 per launch, rocprofv3 --pmc, "
+                            f"separate passes; raw (uncorrected) = {rec['hbm_bytes_per_launch_raw']}; "
+                            f"algorithmic operand+result bytes = {rec.get('algorithmic_bytes_per_launch')}")
     except Exception:  # noqa: BLE001
         pass
     roofline = {

@@ -45,7 +45,7 @@ int itcv_profile_end(void) {
   return (int)itcv::g_prof.size();
 }
 // record i: code = kind | KS<<4 | BM<<8 | up2<<16 | NS<<20 (kind 0 fwd fp32, 1 fwd split-bf16, 2 wgrad fp32,
-// 3 wgrad split-bf16, 4 small-Cout direct, 5 small-Cin direct, 6 fwd on planes, 7 wgrad on planes), algorithmic FLOP,
+// 3 wgrad split-bf16, 4 small-Cout direct, 5 small-Cin direct, 6 fwd on planes, 7 wgrad on planes and 8 band-form fwd on planes -- for 7 and 8 the KS field holds log2(W)), algorithmic FLOP,
 // elapsed milliseconds
 int itcv_profile_get(int i, int* code, double* flop, float* ms) {
   if (i < 0 || i >= (int)itcv::g_prof.size()) return itcv::fail("%s: index out of range", "itcv_profile_get");

@@ -2022,6 +2022,14 @@ struct FwdPlanP2 {
   int ok, bm, mt, nt, cpt, splits, cps, SR, NSEG, NP, NPC, PXB;
   size_t lds;
 };
+static int p2_bm64_mid() {   // ITCV_P2_BM64=0: keep the 128-pixel-tile kernel for the mid-sized layers (diagnostic)
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("ITCV_P2_BM64");
+    v = (e && e[0] == '0') ? 0 : 1;
+  }
+  return v;
+}
 static FwdPlanP2 plan_fwd_p2(int B, int Ci, int H, int W, int Co, int KS, int ns) {
   FwdPlanP2 p;
   memset(&p, 0, sizeof(p));
@@ -2040,11 +2048,13 @@ static FwdPlanP2 plan_fwd_p2(int B, int Ci, int H, int W, int Co, int KS, int ns
   p.NPC = cdiv(p.NP, 64);
   p.PXB = p.NPC * 64;
   if (p.NPC > 7) return p;
+  p.nt = (int)(((long long)B * H * W + 255) / 256);
   p.bm = Co <= 64 ? 64 : 128;
+  // mid-sized layers: 64-row tiles when that fills the chip without split-K and 128-row tiles would not
+  if (p.bm == 128 && cdiv(Co, 128) * p.nt < 192 && cdiv(Co, 64) * p.nt >= 192 && p2_bm64_mid()) p.bm = 64;
   p.lds = ((size_t)3 * 2 * 4 * p.bm + (size_t)2 * 2 * 4 * p.PXB) * 16;
   if (p.lds > 160 * 1024) return p;
   p.mt = cdiv(Co, p.bm);
-  p.nt = (int)(((long long)B * H * W + 255) / 256);
   p.cpt = Ci / 32;
   const int tiles = p.mt * p.nt;
   // mid-sized layers: 128-pixel tiles (conv_fwd_bf16p_kernel) already fill the chip without split-K, 256-pixel
@@ -2379,7 +2389,7 @@ int itcv_conv2d_fwd_bf16p(const void* xplanes, const void* wp, const float* bias
     a.plane_stride = (size_t)B * (Ci / 8) * (up2 ? (H / 2) * (W / 2) : H * W);
     hipStream_t st = S(stream);
     {
-      ProfScope prof(st, 6, KS, p2.bm, up2 ? 1 : 0, ns, 2.0 * B * H * W * (double)Co * Ci * KS * KS);
+      ProfScope prof(st, 8, log2_exact(W), p2.bm, up2 ? 1 : 0, ns, 2.0 * B * H * W * (double)Co * Ci * KS * KS);
       switch (log2_exact(W)) {
         case 3: launch_fwd_p2_w<3>(a, p2.bm, up2, p2.splits, p2.lds, st); break;
         case 4: launch_fwd_p2_w<4>(a, p2.bm, up2, p2.splits, p2.lds, st); break;
@@ -2596,7 +2606,7 @@ int itcv_conv2d_wgrad_bf16p(const void* xplanes, const void* dyplanes, float* dw
   hipStream_t st = S(stream);
   const int blocks = p.tiles_m * p.tiles_n * 3 * p.splits;
   {
-    ProfScope prof(st, 7, KS, p.bm, up2 ? 1 : 0, 2, 2.0 * B * H * W * (double)Co * Ci * KS * KS);
+    ProfScope prof(st, 7, log2_exact(W), p.bm, up2 ? 1 : 0, 2, 2.0 * B * H * W * (double)Co * Ci * KS * KS);
     switch (log2_exact(W)) {
       case 2: launch_wgrad_p<2>(a, p.bm, up2, blocks, st); break;
       case 3: launch_wgrad_p<3>(a, p.bm, up2, blocks, st); break;
