@@ -185,6 +185,19 @@ int itcv_bn_act_bwd_apply(const float* x, const float* dy, const float* mean, co
                           float* dgamma, float* dbeta, int accumulate, int B, int C, int H, int W,
                           float slope, int pool, int up2, void* dx_planes, int ns, void* stream);
 
+/* Single-rank training forms: itcv_bn_train_fwd == itcv_bn_train_stats + itcv_bn_act_fwd and
+ * itcv_bn_train_bwd == itcv_bn_act_bwd_reduce + itcv_bn_act_bwd_apply (count = B*H*W), same arguments and results;
+ * where the planes kernels apply and the reduction is sliced, the apply launch folds the slices itself (two
+ * launches per layer instead of three).  Workspace: itcv_bn_workspace. */
+int itcv_bn_train_fwd(const float* x, const float* gamma, const float* beta, const float* skip, float* y, void* planes,
+                      int ns, int B, int C, int H, int W, float slope, int pool, float eps, float momentum,
+                      float* running_mean, float* running_var, int64_t* num_batches_tracked, float* mean, float* rstd,
+                      void* ws, size_t ws_bytes, void* stream);
+int itcv_bn_train_bwd(const float* x, const float* dy, const float* mean, const float* rstd, const float* gamma,
+                      const float* beta, const float* skip, double* dsums, float* dx, float* dskip, void* dx_planes,
+                      int ns, float* dgamma, float* dbeta, int accumulate, int B, int C, int H, int W, float slope,
+                      int pool, int up2, void* ws, size_t ws_bytes, void* stream);
+
 /* ---- pointwise / resampling ----------------------------------------------------------- */
 int itcv_lrelu_fwd(const float* x, float* y, size_t n, float slope, void* stream);     /* models.py:271 */
 int itcv_lrelu_bwd(const float* x, const float* dy, float* dx, size_t n, float slope, void* stream);

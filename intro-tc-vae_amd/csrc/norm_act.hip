@@ -2,6 +2,8 @@
 // pointwise / resampling kernels of the encoder/decoder stacks.  All HBM-bound: one coalesced
 // pass per tensor, fp64 channel statistics with a deterministic two-stage reduction.
 // Replaces /root/reference/models.py:37-38,48-49,214-216,225,271,284-286,291.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace itcv {
@@ -195,25 +197,73 @@ __global__ void bn_act_fwd_kernel(const float* __restrict__ x, const float* __re
 // (planes[p][b][c/8][h][w], see include/itcv_hip.h): a thread owns 8 channels x 4 output pixels (POOL = 0) or
 // x 2 pooled pixels (POOL = 1), so each pixel's 8 channel values meet in one thread.  The fp32 output is
 // computed with exactly the expressions of bn_act_fwd_kernel (bitwise the same tensor).
-template <int POOL, int NS>
-__global__ void bn_act_fwd_planes_kernel(const float* __restrict__ x, const float* __restrict__ mean,
-                                         const float* __restrict__ rstd, const float* __restrict__ gamma,
-                                         const float* __restrict__ beta, const float* __restrict__ skip,
-                                         float* __restrict__ y, u32x4* __restrict__ planes, int B, int C, int H, int W,
-                                         float slope) {
+// When `st.part` is set the launch also FINALISES the batch statistics from the per-slice partial sums of
+// bn_moments_partial (one launch less per layer): the (<= kStatCh) channels a block touches are folded in slice
+// order by one thread each -- the same fixed-order sum in every block -- and the block that holds the first pixels
+// of image 0 of a channel group records mean / rstd / running statistics for the backward pass.
+constexpr int kStatCh = 64;   // channels per block iteration (8 groups of 8); larger footprints take the two-launch path
+struct BnStatsIn {
+  const double* part;   // [splits][2][C]
+  int splits;
+  double count;
+  float eps, momentum;
+  float* running_mean;
+  float* running_var;
+  int64_t* nbt;
+  float* mean_out;
+  float* rstd_out;
+};
+
+template <int POOL, int NS, bool STATS>
+__global__ __launch_bounds__(256) void bn_act_fwd_planes_kernel(
+    const float* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ rstd,
+    const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ skip,
+    float* __restrict__ y, u32x4* __restrict__ planes, int B, int C, int H, int W, float slope, BnStatsIn st) {
+  __shared__ float s_mean[STATS ? kStatCh : 1], s_rstd[STATS ? kStatCh : 1];
   const int HW = H * W, C8 = C >> 3;
   const int Ho = POOL ? H / 2 : H, Wo = POOL ? W / 2 : W, HWo = Ho * Wo;
   constexpr int PX = POOL ? 2 : 4;                      // output pixels per thread
   const uint32_t per_plane = (uint32_t)HWo / PX, total = (uint32_t)B * C8 * per_plane;
   const size_t plane_stride = (size_t)B * C8 * HWo;
-  for (uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+  for (uint32_t base = blockIdx.x * blockDim.x; base < total; base += gridDim.x * blockDim.x) {
+    const uint32_t idx = base + threadIdx.x;
+    const uint32_t g0 = base / per_plane;                // first (image, channel-group) of this block iteration
+    if (STATS) {
+      __syncthreads();
+      const uint32_t last = min(base + blockDim.x, total) - 1, ng = last / per_plane - g0 + 1;
+      if (threadIdx.x < ng * 8) {
+        const uint32_t g = g0 + threadIdx.x / 8, c = (g % C8) * 8 + (threadIdx.x & 7);
+        double s1 = 0.0, s2 = 0.0;
+        for (int k = 0; k < st.splits; ++k) {
+          s1 += st.part[((size_t)k * 2 + 0) * C + c];
+          s2 += st.part[((size_t)k * 2 + 1) * C + c];
+        }
+        const double m = s1 / st.count;
+        double var = s2 / st.count - m * m;
+        if (var < 0.0) var = 0.0;
+        const float mf = (float)m, rf = (float)(1.0 / sqrt(var + (double)st.eps));
+        s_mean[threadIdx.x] = mf, s_rstd[threadIdx.x] = rf;
+        if (g < (uint32_t)C8 && g * per_plane >= base) {   // image 0, and the group starts inside this block
+          st.mean_out[c] = mf, st.rstd_out[c] = rf;
+          if (st.running_mean) st.running_mean[c] = (1.f - st.momentum) * st.running_mean[c] + st.momentum * mf;
+          if (st.running_var) {
+            const double unbiased = st.count > 1.0 ? var * st.count / (st.count - 1.0) : var;
+            st.running_var[c] = (1.f - st.momentum) * st.running_var[c] + st.momentum * (float)unbiased;
+          }
+          if (c == 0 && st.nbt) st.nbt[0] += 1;
+        }
+      }
+      __syncthreads();
+    }
+    if (idx >= total) continue;
     const uint32_t bc8 = idx / per_plane, pp = idx - bc8 * per_plane;
     const uint32_t b = bc8 / C8, c8 = bc8 - b * C8;
     float o[8][PX];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const int c = c8 * 8 + j;
-      const float sc = gamma[c] * rstd[c], sh = beta[c] - mean[c] * sc;
+      const float mu = STATS ? s_mean[(bc8 - g0) * 8 + j] : mean[c], rs = STATS ? s_rstd[(bc8 - g0) * 8 + j] : rstd[c];
+      const float sc = gamma[c] * rs, sh = beta[c] - mu * sc;
       const size_t bc = (size_t)b * C + c;
       if (POOL == 0) {
         const size_t i = bc * HW + (size_t)pp * 4;
@@ -441,16 +491,50 @@ __global__ void bn_bwd_apply_v4(const float* __restrict__ x, const float* __rest
 
 // bn_bwd_apply_v4 that also emits dx as pre-split planes (for the data- and weight-gradient GEMMs of the conv
 // below): a thread owns 8 channels x 4 pixels; dx is computed with the same expressions (bitwise equal).
-template <int MODE, int NS>
-__global__ void bn_bwd_apply_planes(const float* __restrict__ x, const float* __restrict__ dy,
-                                    const float* __restrict__ mean, const float* __restrict__ rstd,
-                                    const float* __restrict__ gamma, const float* __restrict__ beta,
-                                    const float* __restrict__ skip, const double* __restrict__ dsums, double count,
-                                    float* __restrict__ dx, float* __restrict__ dskip, u32x4* __restrict__ planes,
-                                    int B, int C, int H, int W, float slope, int w_shift) {
+// `sums.part` set: the launch folds the per-slice partial sums of bn_bwd_partial_v4 itself (see BnStatsIn above)
+// and the block holding a channel group's first pixels of image 0 writes dsums and the parameter gradients.
+struct BnBwdSumsIn {
+  const double* part;   // [splits][2][C]
+  int splits;
+  double* dsums_out;
+  float* dgamma;
+  float* dbeta;
+  int accumulate;
+};
+
+template <int MODE, int NS, bool SUMS>
+__global__ __launch_bounds__(256) void bn_bwd_apply_planes(
+    const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ mean,
+    const float* __restrict__ rstd, const float* __restrict__ gamma, const float* __restrict__ beta,
+    const float* __restrict__ skip, const double* __restrict__ dsums, double count, float* __restrict__ dx,
+    float* __restrict__ dskip, u32x4* __restrict__ planes, int B, int C, int H, int W, float slope, int w_shift,
+    BnBwdSumsIn sm) {
+  __shared__ float s_m1[SUMS ? kStatCh : 1], s_m2[SUMS ? kStatCh : 1];
   const uint32_t HW = H * W, C8 = C >> 3, per_plane = HW / 4, total = (uint32_t)B * C8 * per_plane;
   const size_t plane_stride = (size_t)B * C8 * HW;
-  for (uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+  for (uint32_t base = blockIdx.x * blockDim.x; base < total; base += gridDim.x * blockDim.x) {
+    const uint32_t idx = base + threadIdx.x;
+    const uint32_t g0 = base / per_plane;
+    if (SUMS) {
+      __syncthreads();
+      const uint32_t last = min(base + blockDim.x, total) - 1, ng = last / per_plane - g0 + 1;
+      if (threadIdx.x < ng * 8) {
+        const uint32_t g = g0 + threadIdx.x / 8, c = (g % C8) * 8 + (threadIdx.x & 7);
+        double s1 = 0.0, s2 = 0.0;
+        for (int k = 0; k < sm.splits; ++k) {
+          s1 += sm.part[((size_t)k * 2 + 0) * C + c];
+          s2 += sm.part[((size_t)k * 2 + 1) * C + c];
+        }
+        s_m1[threadIdx.x] = (float)(s1 / count), s_m2[threadIdx.x] = (float)(s2 / count);
+        if (g < C8 && g * per_plane >= base) {
+          sm.dsums_out[c] = s1, sm.dsums_out[C + c] = s2;
+          if (sm.dbeta) sm.dbeta[c] = (sm.accumulate ? sm.dbeta[c] : 0.f) + (float)s1;
+          if (sm.dgamma) sm.dgamma[c] = (sm.accumulate ? sm.dgamma[c] : 0.f) + (float)s2;
+        }
+      }
+      __syncthreads();
+    }
+    if (idx >= total) continue;
     const uint32_t bc8 = idx / per_plane, p4 = idx - bc8 * per_plane;
     const uint32_t b = bc8 / C8, c8 = bc8 - b * C8;
     const uint32_t hw = p4 * 4, h = fdiv(hw, W, w_shift), w = hw - h * W;
@@ -460,7 +544,8 @@ __global__ void bn_bwd_apply_planes(const float* __restrict__ x, const float* __
       const uint32_t c = c8 * 8 + j, bc = b * C + c;
       const uint32_t i = bc * HW + hw;
       const float mu = mean[c], rs = rstd[c], ga = gamma[c], be = beta[c];
-      const float m1 = (float)(dsums[c] / count), m2 = (float)(dsums[C + c] / count), gr = ga * rs;
+      const float m1 = SUMS ? s_m1[(bc8 - g0) * 8 + j] : (float)(dsums[c] / count);
+      const float m2 = SUMS ? s_m2[(bc8 - g0) * 8 + j] : (float)(dsums[C + c] / count), gr = ga * rs;
       const float4 xv = *reinterpret_cast<const float4*>(x + i);
       float4 g = upstream4<MODE>(dy, bc, h, w, H, W);
       const float xh0 = (xv.x - mu) * rs, xh1 = (xv.y - mu) * rs, xh2 = (xv.z - mu) * rs, xh3 = (xv.w - mu) * rs;
@@ -577,6 +662,15 @@ static inline int grid_for(size_t n, int per_thread = 1) {
   return b < 1 ? 1 : (int)b;
 }
 
+static inline bool bn_fuse_finalize() {   // ITCV_BN_FUSE=0: always finalise in a separate launch (diagnostic)
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("ITCV_BN_FUSE");
+    v = (e && e[0] == '0') ? 0 : 1;
+  }
+  return v != 0;
+}
+
 static inline int bn_splits(int B, int C, int HW) {
   const size_t total = (size_t)B * HW;
   int s = cdiv(2048, C);
@@ -670,8 +764,8 @@ int itcv_bn_act_fwd(const float* x, const float* mean, const float* rstd, const 
     const dim3 grid(grid_for(threads)), blk(256);
     u32x4* pl = static_cast<u32x4*>(planes);
 #define ITCV_FWD_PLANES(POOL_, NS_)                                                                                   \
-  hipLaunchKernelGGL((bn_act_fwd_planes_kernel<POOL_, NS_>), grid, blk, 0, S(stream), x, mean, rstd, gamma, beta, skip, \
-                     y, pl, B, C, H, W, slope)
+  hipLaunchKernelGGL((bn_act_fwd_planes_kernel<POOL_, NS_, false>), grid, blk, 0, S(stream), x, mean, rstd, gamma, beta, \
+                     skip, y, pl, B, C, H, W, slope, BnStatsIn{})
     if (pool) {
       if (ns == 2) ITCV_FWD_PLANES(1, 2);
       else ITCV_FWD_PLANES(1, 3);
@@ -756,8 +850,8 @@ int itcv_bn_act_bwd_apply(const float* x, const float* dy, const float* mean, co
     const dim3 grid(grid_for(n / 32)), blk(256);
     u32x4* pl = static_cast<u32x4*>(dx_planes);
 #define ITCV_BWD_PLANES(MODE_, NS_)                                                                              \
-  hipLaunchKernelGGL((bn_bwd_apply_planes<MODE_, NS_>), grid, blk, 0, st, x, dy, mean, rstd, gamma, beta, skip, dsums, \
-                     count, dx, dskip, pl, B, C, H, W, slope, wsh)
+  hipLaunchKernelGGL((bn_bwd_apply_planes<MODE_, NS_, false>), grid, blk, 0, st, x, dy, mean, rstd, gamma, beta, skip,  \
+                     dsums, count, dx, dskip, pl, B, C, H, W, slope, wsh, BnBwdSumsIn{})
 #define ITCV_BWD_PLANES_NS(MODE_)        \
   do {                                   \
     if (ns == 2) ITCV_BWD_PLANES(MODE_, 2); \
@@ -798,6 +892,97 @@ int itcv_bn_act_bwd_apply(const float* x, const float* dy, const float* mean, co
                        local_dsums ? local_dsums : dsums, dgamma, dbeta, C, accumulate);
     ITCV_CHECK_LAUNCH("itcv_bn_act_bwd_apply(param grads)");
   }
+  return 0;
+}
+
+// ---- single-rank training forms: statistics + apply (forward), sums + apply (backward) ----------------------
+// Same results as itcv_bn_train_stats + itcv_bn_act_fwd (resp. itcv_bn_act_bwd_reduce + _apply); where the planes
+// kernels apply and the reduction is sliced, the apply launch folds the slices itself: two launches instead of three.
+int itcv_bn_train_fwd(const float* x, const float* gamma, const float* beta, const float* skip, float* y, void* planes,
+                      int ns, int B, int C, int H, int W, float slope, int pool, float eps, float momentum,
+                      float* running_mean, float* running_var, int64_t* num_batches_tracked, float* mean, float* rstd,
+                      void* ws, size_t ws_bytes, void* stream) {
+  ITCV_REQUIRE(x && gamma && beta && mean && rstd && (y || planes) && B > 0 && C > 0 && H > 0 && W > 0, "itcv_bn_train_fwd");
+  const int HW = H * W, splits = bn_splits(B, C, HW);
+  const int per_plane = pool ? (HW / 4) / 2 : HW / 4;
+  const bool fusable = planes && (ns == 2 || ns == 3) && itcv_bn_act_planes_supported(C, H, W, pool) && splits > 1 &&
+                       per_plane >= 64 && (size_t)B * C * HW < (1ull << 31) && bn_fuse_finalize();
+  if (!fusable) {
+    if (int e = itcv_bn_train_stats(x, B, C, HW, eps, momentum, running_mean, running_var, num_batches_tracked, mean,
+                                    rstd, ws, ws_bytes, stream))
+      return e;
+    return itcv_bn_act_fwd(x, mean, rstd, gamma, beta, skip, y, B, C, H, W, slope, pool, planes, ns, stream);
+  }
+  ITCV_REQUIRE(ws && ws_bytes >= (size_t)splits * 2 * C * sizeof(double), "itcv_bn_train_fwd(workspace)");
+  double* part = static_cast<double*>(ws);
+  hipLaunchKernelGGL(bn_moments_partial<false>, dim3(C, splits), dim3(kRedThreads), 0, S(stream), x, part, B, C, HW,
+                     splits, ilog2_exact(HW), BnFinal{});
+  ITCV_CHECK_LAUNCH("itcv_bn_train_fwd(partials)");
+  const BnStatsIn st{part, splits, (double)B * HW, eps, momentum, running_mean, running_var, num_batches_tracked, mean, rstd};
+  const size_t threads = (size_t)B * (C / 8) * per_plane;
+  const dim3 grid(grid_for(threads)), blk(256);
+  u32x4* pl = static_cast<u32x4*>(planes);
+#define ITCV_FWD_FUSED(POOL_, NS_)                                                                                   \
+  hipLaunchKernelGGL((bn_act_fwd_planes_kernel<POOL_, NS_, true>), grid, blk, 0, S(stream), x, mean, rstd, gamma, beta, \
+                     skip, y, pl, B, C, H, W, slope, st)
+  if (pool) {
+    if (ns == 2) ITCV_FWD_FUSED(1, 2);
+    else ITCV_FWD_FUSED(1, 3);
+  } else {
+    if (ns == 2) ITCV_FWD_FUSED(0, 2);
+    else ITCV_FWD_FUSED(0, 3);
+  }
+#undef ITCV_FWD_FUSED
+  ITCV_CHECK_LAUNCH("itcv_bn_train_fwd(apply)");
+  return 0;
+}
+
+int itcv_bn_train_bwd(const float* x, const float* dy, const float* mean, const float* rstd, const float* gamma,
+                      const float* beta, const float* skip, double* dsums, float* dx, float* dskip, void* dx_planes,
+                      int ns, float* dgamma, float* dbeta, int accumulate, int B, int C, int H, int W, float slope,
+                      int pool, int up2, void* ws, size_t ws_bytes, void* stream) {
+  ITCV_REQUIRE(x && dy && mean && rstd && gamma && beta && dsums && (dx || dx_planes) && B > 0 && C > 0,
+               "itcv_bn_train_bwd");
+  ITCV_REQUIRE(!(pool && up2), "itcv_bn_train_bwd(pool and up2 are exclusive)");
+  const int HW = H * W, splits = bn_splits(B, C, HW);
+  const size_t n = (size_t)B * C * HW;
+  const bool vec = (W % 4 == 0) && n < (1ull << 31);
+  const bool fusable = dx_planes && (ns == 2 || ns == 3) && vec && itcv_bn_act_planes_supported(C, H, W, 0) &&
+                       splits > 1 && HW / 4 >= 64 && bn_fuse_finalize();
+  if (!fusable) {
+    if (int e = itcv_bn_act_bwd_reduce(x, dy, mean, rstd, gamma, beta, skip, dsums, dgamma, dbeta, accumulate, B, C, H, W,
+                                       slope, pool, up2, ws, ws_bytes, stream))
+      return e;
+    return itcv_bn_act_bwd_apply(x, dy, mean, rstd, gamma, beta, skip, dsums, nullptr, (double)B * HW, dx, dskip, nullptr,
+                                 nullptr, 0, B, C, H, W, slope, pool, up2, dx_planes, ns, stream);
+  }
+  if (pool) ITCV_REQUIRE(H % 2 == 0 && W % 2 == 0, "itcv_bn_train_bwd(pool)");
+  ITCV_REQUIRE(ws && ws_bytes >= (size_t)splits * 2 * C * sizeof(double), "itcv_bn_train_bwd(workspace)");
+  double* part = static_cast<double*>(ws);
+  hipStream_t st = S(stream);
+  const int wsh = ilog2_exact(W), hwsh = ilog2_exact(HW);
+  const BnBwdSumsIn sm{part, splits, dsums, dgamma, dbeta, accumulate};
+  const dim3 rgrid(C, splits), agrid(grid_for(n / 32)), blk(256);
+  u32x4* pl = static_cast<u32x4*>(dx_planes);
+  const double count = (double)B * HW;
+#define ITCV_BWD_FUSED(MODE_, NS_)                                                                                    \
+  do {                                                                                                                \
+    hipLaunchKernelGGL((bn_bwd_partial_v4<MODE_, false>), rgrid, dim3(kRedThreads), 0, st, x, dy, mean, rstd, gamma,   \
+                       beta, skip, part, B, C, H, W, slope, splits, wsh, hwsh, BnBwdFinal{});                         \
+    hipLaunchKernelGGL((bn_bwd_apply_planes<MODE_, NS_, true>), agrid, blk, 0, st, x, dy, mean, rstd, gamma, beta, skip, \
+                       static_cast<const double*>(nullptr), count, dx, dskip, pl, B, C, H, W, slope, wsh, sm);        \
+  } while (0)
+#define ITCV_BWD_FUSED_NS(MODE_)            \
+  do {                                      \
+    if (ns == 2) ITCV_BWD_FUSED(MODE_, 2);  \
+    else ITCV_BWD_FUSED(MODE_, 3);          \
+  } while (0)
+  if (pool) ITCV_BWD_FUSED_NS(1);
+  else if (up2) ITCV_BWD_FUSED_NS(2);
+  else ITCV_BWD_FUSED_NS(0);
+#undef ITCV_BWD_FUSED_NS
+#undef ITCV_BWD_FUSED
+  ITCV_CHECK_LAUNCH("itcv_bn_train_bwd");
   return 0;
 }
 

@@ -531,21 +531,6 @@ class BnActFn(Function):
         mean = torch.empty((C,), dtype=F32, device=dev)
         rstd = torch.empty((C,), dtype=F32, device=dev)
         world = _world(group) if training else 1
-        if training and world == 1:
-            nws = lib.itcv_bn_workspace(B, C, H * W)
-            ws = _ws(nws, dev)
-            call("itcv_bn_train_stats", ptr(x), B, C, H * W, float(eps), float(momentum), ptr(running_mean),
-                 ptr(running_var), ptr(nbt), ptr(mean), ptr(rstd), ptr(ws), nws, stream())
-        elif training:
-            nws = lib.itcv_bn_workspace(B, C, H * W)
-            ws = _ws(nws, dev)
-            sums = torch.empty((2 * C,), dtype=torch.float64, device=dev)
-            call("itcv_bn_moments", ptr(x), ptr(sums), B, C, H * W, ptr(ws), nws, stream())
-            dist.all_reduce(sums, group=group)
-            call("itcv_bn_finalize", ptr(sums), float(B * H * W * world), float(eps), float(momentum),
-                 ptr(running_mean), ptr(running_var), ptr(nbt), ptr(mean), ptr(rstd), C, stream())
-        else:
-            call("itcv_bn_eval_stats", ptr(running_mean), ptr(running_var), float(eps), ptr(mean), ptr(rstd), C, stream())
         oshape = (B, C, H // 2, W // 2) if pool else (B, C, H, W)
         y = torch.empty(oshape, dtype=F32, device=dev)
         yp = None
@@ -553,8 +538,27 @@ class BnActFn(Function):
             yp = torch.empty(lib.itcv_planes_bytes(B, C, oshape[2] * oshape[3], out_planes) // 4, dtype=torch.int32,
                              device=dev)
         write_y = out_fp32 or yp is None or _POISON[0]
-        call("itcv_bn_act_fwd", ptr(x), ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), ptr(skip),
-             ptr(y) if write_y else None, B, C, H, W, float(slope), int(pool), ptr(yp), int(out_planes), stream())
+        if training and world == 1:
+            # statistics + apply in one call (the apply launch folds the sliced reduction where it can)
+            nws = lib.itcv_bn_workspace(B, C, H * W)
+            ws = _ws(nws, dev)
+            call("itcv_bn_train_fwd", ptr(x), ptr(gamma), ptr(beta), ptr(skip), ptr(y) if write_y else None, ptr(yp),
+                 int(out_planes), B, C, H, W, float(slope), int(pool), float(eps), float(momentum), ptr(running_mean),
+                 ptr(running_var), ptr(nbt), ptr(mean), ptr(rstd), ptr(ws), nws, stream())
+        else:
+            if training:
+                nws = lib.itcv_bn_workspace(B, C, H * W)
+                ws = _ws(nws, dev)
+                sums = torch.empty((2 * C,), dtype=torch.float64, device=dev)
+                call("itcv_bn_moments", ptr(x), ptr(sums), B, C, H * W, ptr(ws), nws, stream())
+                dist.all_reduce(sums, group=group)
+                call("itcv_bn_finalize", ptr(sums), float(B * H * W * world), float(eps), float(momentum),
+                     ptr(running_mean), ptr(running_var), ptr(nbt), ptr(mean), ptr(rstd), C, stream())
+            else:
+                call("itcv_bn_eval_stats", ptr(running_mean), ptr(running_var), float(eps), ptr(mean), ptr(rstd), C,
+                     stream())
+            call("itcv_bn_act_fwd", ptr(x), ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), ptr(skip),
+                 ptr(y) if write_y else None, B, C, H, W, float(slope), int(pool), ptr(yp), int(out_planes), stream())
         if yp is not None:
             if _POISON[0] and not out_fp32:
                 y.fill_(float("nan"))
@@ -592,21 +596,24 @@ class BnActFn(Function):
             dgamma = torch.empty_like(gamma) if ctx.needs_input_grad[1] else None
             dbeta = torch.empty_like(beta) if ctx.needs_input_grad[2] else None
             pg, pb, acc = dgamma, dbeta, 0
-        call("itcv_bn_act_bwd_reduce", ptr(x), ptr(dy), ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), ptr(skip),
-             ptr(local), ptr(pg), ptr(pb), acc, B, C, H, W, slope, pool, 0, ptr(ws), nws, stream())
-        total = local
-        if world > 1:
-            total = local.clone()
-            dist.all_reduce(total, group=group)
         dx = torch.empty_like(x)
         dskip = torch.empty_like(x) if (skip is not None and ctx.needs_input_grad[3]) else None
         dxp = None
         if grad_planes:
             dxp = torch.empty(lib.itcv_planes_bytes(B, C, H * W, grad_planes) // 4, dtype=torch.int32, device=dev)
         write_dx = grad_fp32 or dxp is None or _POISON[0]
-        call("itcv_bn_act_bwd_apply", ptr(x), ptr(dy), ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), ptr(skip),
-             ptr(total), None, float(B * H * W * world), ptr(dx) if write_dx else None, ptr(dskip), None, None, 0, B,
-             C, H, W, slope, pool, 0, ptr(dxp), grad_planes, stream())
+        if world == 1:
+            call("itcv_bn_train_bwd", ptr(x), ptr(dy), ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), ptr(skip), ptr(local),
+                 ptr(dx) if write_dx else None, ptr(dskip), ptr(dxp), grad_planes, ptr(pg), ptr(pb), acc, B, C, H, W,
+                 slope, pool, 0, ptr(ws), nws, stream())
+        else:
+            call("itcv_bn_act_bwd_reduce", ptr(x), ptr(dy), ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), ptr(skip),
+                 ptr(local), ptr(pg), ptr(pb), acc, B, C, H, W, slope, pool, 0, ptr(ws), nws, stream())
+            total = local.clone()
+            dist.all_reduce(total, group=group)
+            call("itcv_bn_act_bwd_apply", ptr(x), ptr(dy), ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), ptr(skip),
+                 ptr(total), None, float(B * H * W * world), ptr(dx) if write_dx else None, ptr(dskip), None, None, 0, B,
+                 C, H, W, slope, pool, 0, ptr(dxp), grad_planes, stream())
         if dxp is not None:
             if _POISON[0] and not grad_fp32:
                 dx.fill_(float("nan"))
