@@ -1738,6 +1738,46 @@ __global__ void wgrad_p_reduce(const float* __restrict__ slab, float* __restrict
   }
 }
 
+// Same reduce for SMALL weight tensors with many slices (the 5x5 layers: 4800 elements x 256 slices): one thread
+// per element would walk the slices as one long latency chain, so 16 threads share an element (slice s -> thread
+// s % 16, each in ascending order) and their partial sums are folded in a fixed order through LDS.
+__global__ __launch_bounds__(256) void splitk_reduce_wgrad_small(const float* __restrict__ slab, float* __restrict__ dw,
+                                                                 int Co, int Ci, int KK, int Cip, int cb, int Np,
+                                                                 size_t slab_stride, int splits, int accumulate,
+                                                                 int swapped) {
+  __shared__ float part[16][17];
+  const int e = threadIdx.x & 15, g = threadIdx.x >> 4;
+  const size_t total = (size_t)Co * Ci * KK, i = (size_t)blockIdx.x * 16 + e;
+  float s = 0.f;
+  if (i < total) {
+    int tap = (int)(i % KK);
+    const size_t r = i / KK;
+    int ci = (int)(r % Ci), co = (int)(r / Ci);
+    if (swapped) {
+      const int tmp = ci;
+      ci = co, co = tmp, tap = KK - 1 - tap;
+    }
+    int col;
+    if (cb == 128) {
+      const int per_tap = Cip / 128;
+      col = (tap * per_tap + ci / 128) * 128 + (ci & 127);
+    } else {
+      const int tpb = 128 / cb;
+      col = (tap / tpb) * 128 + (tap % tpb) * cb + ci;
+    }
+    const float* p = slab + (size_t)co * Np + col;
+    for (int k = g; k < splits; k += 16) s += p[(size_t)k * slab_stride];
+  }
+  part[g][e] = s;
+  __syncthreads();
+  if (g == 0 && i < total) {
+    float t = accumulate ? dw[i] : 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t += part[k][e];
+    dw[i] = t;
+  }
+}
+
 // dw[co][ci][tap] (+)= sum_s slab[s][co][column(tap, ci)]
 // swapped: the GEMM ran with the operands exchanged (rows = ci, columns = (flipped tap, co)); Co/Ci here are
 // always those of dw
@@ -2509,8 +2549,13 @@ int itcv_conv2d_wgrad(const float* x, const float* dy, float* dw, int B, int Ci,
   ITCV_CHECK_LAUNCH("itcv_conv2d_wgrad");
   const size_t dw_elems = (size_t)Co * Ci * KS * KS;
   const int blocks = (int)(cdivz(dw_elems, 256) < 2048 ? cdivz(dw_elems, 256) : 2048);
-  hipLaunchKernelGGL(splitk_reduce_wgrad, dim3(blocks), dim3(256), 0, st, static_cast<const float*>(ws), dw, Co_dw,
-                     Ci_dw, KS * KS, p.cip, p.cb, a.Np, slab, p.splits, accumulate, swapped ? 1 : 0);
+  if (dw_elems <= 65536 && p.splits >= 32)
+    hipLaunchKernelGGL(splitk_reduce_wgrad_small, dim3((int)cdivz(dw_elems, 16)), dim3(256), 0, st,
+                       static_cast<const float*>(ws), dw, Co_dw, Ci_dw, KS * KS, p.cip, p.cb, a.Np, slab, p.splits,
+                       accumulate, swapped ? 1 : 0);
+  else
+    hipLaunchKernelGGL(splitk_reduce_wgrad, dim3(blocks), dim3(256), 0, st, static_cast<const float*>(ws), dw, Co_dw,
+                       Ci_dw, KS * KS, p.cip, p.cb, a.Np, slab, p.splits, accumulate, swapped ? 1 : 0);
   ITCV_CHECK_LAUNCH("itcv_conv2d_wgrad(reduce)");
   return 0;
 }
