@@ -212,8 +212,8 @@ def main():
         if rec:
             traffic = rec["hbm_bytes_per_launch_fetch_x2"]
             traffic_note = ("profiles/r01_pmc_traffic.json: (2*FETCH_SIZE + WRITE_SIZE)*1024 per launch, rocprofv3 --pmc, "
-                            f"separate passes; raw (uncorrected) = {rec['hbm_bytes_per_launch_raw']}; "
-                            f"algorithmic operand+result bytes = {rec.get('algorithmic_bytes_per_launch')}")
+                            f"separate passes; raw (uncorrected) = {rec['hbm_bytes_per_launch_raw']}; algorithmic operand + "
+                            "result bytes per launch: B*H*W*(4*Ci + 4*Co) + packed weights (DESIGN.md section 6)")
     except Exception:  # noqa: BLE001
         pass
     roofline = {
