@@ -997,6 +997,7 @@ struct ConvArgsP2 {
   int SR, NSEG, NP, NPC, PXB;    // band geometry: segment rows, segments, halo pixels, 64-chunk pieces, LDS row stride
   int h_shift;
   size_t slab_stride, plane_stride;
+  int debug;   // diagnostic only (ITCV_ABLATE & 64): block 0 / 100 report main-loop shader cycles and 100 MHz ticks in y[0..3]
 };
 
 template <int LOG2W, int BM, bool UP2>
@@ -1108,8 +1109,10 @@ __global__ __launch_bounds__(768) void conv_fwd_bf16p2_kernel(ConvArgsP2 a) {
     for (int j = 0; j < TN; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  const long long dbg_c00 = a.debug ? clock64() : 0;
   __builtin_amdgcn_s_barrier();
   int buf = 0;
+  const long long dbg_c0 = a.debug ? clock64() : 0, dbg_w0 = a.debug ? wall_clock64() : 0;
   for (int cib = c0; cib < c1; ++cib) {
     const uint32_t bb = band_base + (uint32_t)(buf * BSZ) * 16u;
 #pragma unroll
@@ -1146,6 +1149,11 @@ __global__ __launch_bounds__(768) void conv_fwd_bf16p2_kernel(ConvArgsP2 a) {
       __builtin_amdgcn_s_barrier();
     }
     buf ^= 1;
+  }
+  if (a.debug && t == 0 && (bid == 0 || bid == 100)) {
+    float* d = a.y + (bid ? 4 : 0);
+    d[0] = (float)(clock64() - dbg_c0), d[1] = (float)(wall_clock64() - dbg_w0), d[2] = (float)(dbg_c0 - dbg_c00), d[3] = (float)nk;
+    return;
   }
 
   float* out = a.y + (size_t)sk * a.slab_stride;
@@ -2427,6 +2435,14 @@ int itcv_conv2d_fwd_bf16p(const void* xplanes, const void* wp, const float* bias
     a.h_shift = log2_exact(H);
     a.slab_stride = p2.splits > 1 ? out_elems : 0;
     a.plane_stride = (size_t)B * (Ci / 8) * (up2 ? (H / 2) * (W / 2) : H * W);
+    {
+      static int dbg = -1;
+      if (dbg < 0) {
+        const char* e = getenv("ITCV_ABLATE");
+        dbg = (e && (atoi(e) & 64)) ? 1 : 0;
+      }
+      a.debug = dbg;
+    }
     hipStream_t st = S(stream);
     {
       ProfScope prof(st, 8, log2_exact(W), p2.bm, up2 ? 1 : 0, ns, 2.0 * B * H * W * (double)Co * Ci * KS * KS);

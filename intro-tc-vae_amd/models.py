@@ -26,10 +26,31 @@ LRELU_SLOPE = 0.2
 
 
 # ------------------------------------------------------------------------------ layers
+# Construction-time only: the reference sizes the encoder's fc layer by pushing a zero image through `main` on the
+# CPU in train mode (models.py:229,235-238), which also warms every encoder BatchNorm's running statistics.  While
+# this flag is set the layers below run their torch parent classes on the CPU so that the same pass can be made
+# here (inception blocks: the biased 1x1 convs make the warm-up statistics weight dependent).  Never set in a step.
+_CPU_WARMUP = [False]
+
+
+def _add(a, b):
+    return a + b if _CPU_WARMUP[0] else HF.AddFn.apply(a, b)
+
+
+def _upsample2(x):
+    return nn.functional.interpolate(x, scale_factor=2, mode="nearest") if _CPU_WARMUP[0] else HF.Upsample2Fn.apply(x)
+
+
+def _avgpool2(x):
+    return nn.functional.avg_pool2d(x, 2) if _CPU_WARMUP[0] else HF.AvgPool2Fn.apply(x)
+
+
 class HipConv2d(nn.Conv2d):
     """nn.Conv2d (stride 1, 'same' padding) on the implicit-GEMM MFMA kernel."""
 
     def forward(self, x, up2=False):
+        if _CPU_WARMUP[0]:
+            return nn.Conv2d.forward(self, _upsample2(x) if up2 else x)
         return HF.Conv2dFn.apply(x, self.weight, self.bias, bool(up2))
 
 
@@ -48,6 +69,11 @@ class HipBatchNorm2d(nn.BatchNorm2d):
         """``out_mode`` / ``grad_mode`` = (planes, fp32): number of bf16 planes in which the output / the input
         gradient are additionally written for the neighbouring conv GEMMs (0 = none), and whether the fp32
         tensor itself is still needed (False: only the planes are written); see hipvae.functional."""
+        if _CPU_WARMUP[0]:
+            y = nn.BatchNorm2d.forward(self, x)
+            y = y if skip is None else y + skip
+            y = nn.functional.leaky_relu(y, slope) if slope != 1.0 else y
+            return nn.functional.avg_pool2d(y, 2) if pool else y
         return HF.BnActFn.apply(x, self.weight, self.bias, skip, self.running_mean, self.running_var,
                                 self.num_batches_tracked, self.eps, self.momentum, slope, bool(pool), self.training,
                                 self.sync_group, int(out_mode[0]), int(grad_mode[0]), bool(out_mode[1]),
@@ -56,12 +82,14 @@ class HipBatchNorm2d(nn.BatchNorm2d):
 
 class HipLeakyReLU(nn.LeakyReLU):
     def forward(self, x):
+        if _CPU_WARMUP[0]:
+            return nn.functional.leaky_relu(x, self.negative_slope)
         return HF.LeakyReluFn.apply(x, self.negative_slope)
 
 
 class HipAvgPool2d(nn.AvgPool2d):
     def forward(self, x):
-        return HF.AvgPool2Fn.apply(x)
+        return _avgpool2(x)
 
 
 class HipUpsample(nn.Upsample):
@@ -179,11 +207,11 @@ class InceptionResnetBlock(nn.Module):
 
     def forward(self, x, pool=False, up2=False, consumer=None, consumer_up2=False):
         if up2:
-            x = HF.Upsample2Fn.apply(x)
+            x = _upsample2(x)
         skip = self.conv_expand(x) if self.conv_expand is not None else x
         y = torch.cat((self.branch_0(x), self.branch_1(x)), dim=1)
-        y = self.relu(HF.AddFn.apply(self.conv(y), skip))
-        return HF.AvgPool2Fn.apply(y) if pool else y
+        y = self.relu(_add(self.conv(y), skip))
+        return _avgpool2(y) if pool else y
 
 
 _BLOCKS = {"conv": ConvolutionalBlock, "res": ResidualBlock, "inception": InceptionResnetBlock}
@@ -235,7 +263,17 @@ class Encoder(nn.Module):
         num_batches_tracked = 1.  With bias-free convolutions the activations of that pass are
         identically zero, so the buffers are set directly (shape arithmetic replaces the pass)."""
         if arch == "inception":
-            raise NotImplementedError("inception blocks: encoder BatchNorm warm-up state not implemented yet")
+            # biased 1x1 convs: the warm-up activations depend on the freshly initialised weights -- make the pass
+            was_training = self.training
+            self.train()
+            _CPU_WARMUP[0] = True
+            try:
+                with torch.no_grad():
+                    self.main(torch.zeros(1, self.cdim, self.image_size, self.image_size))
+            finally:
+                _CPU_WARMUP[0] = False
+                self.train(was_training)
+            return
         for m in self.main.modules():
             if isinstance(m, nn.BatchNorm2d):
                 m.running_var.fill_(0.9)
@@ -244,13 +282,14 @@ class Encoder(nn.Module):
     def forward(self, x):
         if self.fused:
             blocks = [getattr(self.main, name) for name, _ in self._stages]
-            res_block = isinstance(blocks[0], ResidualBlock)    # its skip path reads the fp32 tensor
-            mode = HF.conv_input_mode(blocks[0].conv1, x.size(0), x.size(2) // 2, x.size(3) // 2)
+            res_block = not isinstance(blocks[0], ConvolutionalBlock)    # skip paths / branches read the fp32 tensor
+            first = getattr(blocks[0], "conv1", None)
+            mode = HF.conv_input_mode(first, x.size(0), x.size(2) // 2, x.size(3) // 2) if first is not None else (0, True)
             y = self.main[1](self.main[0](x), slope=LRELU_SLOPE, pool=True,
                              out_mode=(mode[0], True) if res_block else mode,
                              grad_mode=(HF.conv_grad_planes_ns(self.main[0], x.requires_grad), True))
             for k, (name, pooled) in enumerate(self._stages):
-                nxt = blocks[k + 1].conv1 if k + 1 < len(blocks) else None
+                nxt = getattr(blocks[k + 1], "conv1", None) if k + 1 < len(blocks) else None
                 y = blocks[k](y, pool=pooled, consumer=nxt)
         else:
             y = self.main(x)
@@ -293,7 +332,7 @@ class Decoder(nn.Module):
         if self.fused:
             blocks = [getattr(self.main, name) for name in self._stages]
             for k, blk in enumerate(blocks):   # the upsample before block k folds into its conv
-                nxt = blocks[k + 1].conv1 if k + 1 < len(blocks) else self.main.predict
+                nxt = getattr(blocks[k + 1], "conv1", None) if k + 1 < len(blocks) else self.main.predict
                 y = blk(y, up2=k > 0, consumer=nxt, consumer_up2=k + 1 < len(blocks))
             y = self.main.sigmoid(self.main.predict(y))
         else:

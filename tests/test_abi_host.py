@@ -63,7 +63,7 @@ def test_no_cpu_fallback():
     assert "import oracle" not in src and "from oracle" not in src, "the product must not touch the oracle"
 
 
-@pytest.mark.parametrize("arch", ["conv", "res"])
+@pytest.mark.parametrize("arch", ["conv", "res", "inception"])
 def test_init_and_state_dict_equal_reference(arch):
     import models
     g = np.load(os.path.join(GOLDEN, f"model_{arch}.npz"))

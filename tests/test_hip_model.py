@@ -40,7 +40,7 @@ def build(arch, state):
 
 
 @pytest.mark.parametrize("fused", [True, False])
-@pytest.mark.parametrize("arch", ["conv", "res"])
+@pytest.mark.parametrize("arch", ["conv", "res", "inception"])
 def test_model_forward_backward_golden(arch, fused):
     import ops
     g = np.load(os.path.join(GOLDEN, f"model_{arch}.npz"))
