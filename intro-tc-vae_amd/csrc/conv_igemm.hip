@@ -1585,13 +1585,14 @@ __device__ __forceinline__ void tr_read8(bf16x8& dst, uint32_t addr0, uint32_t a
   dst = __builtin_bit_cast(bf16x8, v);
 }
 
-template <int LOG2W, bool UP2, int BM>
+template <int LOG2W, bool UP2, int BM, int BN>
 __global__ __launch_bounds__(768) void conv_wgrad_bf16p_kernel(WgradArgsP a) {
   constexpr int W = 1 << LOG2W, NR = 64 >> LOG2W, WP = W + 2, NP = NR * WP;   // band: NR rows x (W+2) columns
   constexpr int PXA = 68, PXB = ((NP + 11) / 16) * 16 + 4;                     // row strides = 4 (mod 16) chunks: conflict-free tr reads
   static_assert(PXB >= NP && PXB % 16 == 4, "band stride");
-  constexpr int BN = 8192 / BM, ACH = BM / 8, BCH = BN / 8;                    // 128 x 64 or 64 x 128 (co x ci)
-  constexpr int WMn = BM / 32, WNn = 8 / WMn;
+  constexpr int ACH = BM / 8, BCH = BN / 8;                                    // 128 x 128, 128 x 64 or 64 x 128 (co x ci)
+  constexpr int WMn = BM / 32, WNn = 8 / WMn, TNw = BN / (32 * WNn);          // 32 x 32*TNw accumulators x 3 taps per wave
+  static_assert(TNw >= 1 && BN == 32 * WNn * TNw, "wave tiling");
   constexpr int ASZ = 2 * ACH * PXA, BSZ = 2 * BCH * PXB, SSZ = ASZ + BSZ;     // chunks per stage
   extern __shared__ u32x4 smem[];
 
@@ -1667,15 +1668,17 @@ __global__ __launch_bounds__(768) void conv_wgrad_bf16p_kernel(WgradArgsP a) {
   const int wm = wid / WNn, wn = wid % WNn;
   const int G = lane >> 4, i16 = lane & 15, q = i16 >> 2, pp = i16 & 3, half = G >> 1, rb = G & 1;
   const int l31 = lane & 31;
-  f32x16 acc[3];
+  f32x16 acc[3][TNw];
 #pragma unroll
   for (int tp = 0; tp < 3; ++tp)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[tp][r] = 0.f;
+    for (int j = 0; j < TNw; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[tp][j][r] = 0.f;
   if (s0 < s1) {
     // byte offsets inside a stage of this lane's transposed reads (plane 0, k-step 0, first half)
     const uint32_t aoff = (uint32_t)(((4 * wm + 2 * rb + (pp >> 1)) * PXA + half * 8 + q) * 16 + (pp & 1) * 8);
-    const uint32_t boff = (uint32_t)((ASZ + (4 * wn + 2 * rb + (pp >> 1)) * PXB) * 16 + (pp & 1) * 8);
+    const uint32_t boff = (uint32_t)((ASZ + (4 * wn * TNw + 2 * rb + (pp >> 1)) * PXB) * 16 + (pp & 1) * 8);
     // band index of pixel k = kk*16 + half*8 + s*4 + q, for the 8 (kk, s) pairs, centre tap
     uint32_t hidx16[8];
 #pragma unroll
@@ -1696,19 +1699,21 @@ __global__ __launch_bounds__(768) void conv_wgrad_bf16p_kernel(WgradArgsP a) {
           tr_read8(af[pl], ad, ad + 64);
         }
 #pragma unroll
-        for (int tp = 0; tp < 3; ++tp) {
-          bf16x8 bfr[2];
+        for (int tp = 0; tp < 3; ++tp)
 #pragma unroll
-          for (int pl = 0; pl < 2; ++pl) {
-            const uint32_t bd = sb + boff + (uint32_t)(pl * BCH * PXB * 16 + (tp - 1) * 16);
-            tr_read8(bfr[pl], bd + hidx16[kk * 2], bd + hidx16[kk * 2 + 1]);
+          for (int j = 0; j < TNw; ++j) {
+            bf16x8 bfr[2];
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) {
+              const uint32_t bd = sb + boff + (uint32_t)((pl * BCH + 4 * j) * PXB * 16 + (tp - 1) * 16);
+              tr_read8(bfr[pl], bd + hidx16[kk * 2], bd + hidx16[kk * 2 + 1]);
+            }
+            f32x16 c = acc[tp][j];
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bfr[1], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], bfr[0], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bfr[0], c, 0, 0, 0);
+            acc[tp][j] = c;
           }
-          f32x16 c = acc[tp];
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bfr[1], c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], bfr[0], c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bfr[0], c, 0, 0, 0);
-          acc[tp] = c;
-        }
       }
       stage ^= 1;
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -1716,15 +1721,17 @@ __global__ __launch_bounds__(768) void conv_wgrad_bf16p_kernel(WgradArgsP a) {
     }
   }
   // slab[split][tap][co][ci]
-  const int ci = ci0 + 32 * wn + l31;
-  if (ci < a.Ci) {
+#pragma unroll
+  for (int j = 0; j < TNw; ++j) {
+    const int ci = ci0 + 32 * (wn * TNw + j) + l31;
+    if (ci >= a.Ci) continue;
 #pragma unroll
     for (int tp = 0; tp < 3; ++tp) {
       float* out = a.slab + ((size_t)(split * 9 + dhi * 3 + tp) * a.Co) * a.Ci + ci;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int co = co0 + 32 * wm + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        if (co < a.Co) out[(size_t)co * a.Ci] = acc[tp][r];
+        if (co < a.Co) out[(size_t)co * a.Ci] = acc[tp][j][r];
       }
     }
   }
@@ -2146,12 +2153,24 @@ static void launch_fwd_p2_w(const ConvArgsP2& a, int bm, int up2, int splits, si
 }
 
 struct WgPlanP {
-  int bm, tiles_m, tiles_n, steps, splits, sps;
+  int bm, bn, tiles_m, tiles_n, steps, splits, sps;
 };
+static int wgrad_p_wide() {   // ITCV_WGP_WIDE=0: 128 x 64 tiles only (diagnostic)
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("ITCV_WGP_WIDE");
+    v = (e && e[0] == '0') ? 0 : 1;
+  }
+  return v;
+}
 static WgPlanP plan_wgrad_p(int B, int Ci, int H, int W, int Co) {
   WgPlanP p;
   p.bm = (Co <= 64 && Ci >= 128) ? 64 : 128;    // 64 x 128 (co x ci) tiles when the output side is narrow
-  p.tiles_m = cdiv(Co, p.bm), p.tiles_n = cdiv(Ci, 8192 / p.bm);
+  p.bn = 8192 / p.bm;
+  // 128 x 128 tiles halve the operand bytes per MFMA (the 128 x 64 form runs near the ~30 B/clk/CU ingest limit) but
+  // double the slab a block writes: measured faster only for the widest layers, where few K slices are needed
+  if (p.bm == 128 && Ci >= 512 && Co >= 256 && W >= 8 && wgrad_p_wide()) p.bn = 128;
+  p.tiles_m = cdiv(Co, p.bm), p.tiles_n = cdiv(Ci, p.bn);
   p.steps = (int)(((long long)B * H * W) / 64);
   const int T = p.tiles_m * p.tiles_n * 3;
   int splits = 256 / T;                       // one 768-thread block per CU
@@ -2162,27 +2181,31 @@ static WgPlanP plan_wgrad_p(int B, int Ci, int H, int W, int Co) {
   return p;
 }
 
-template <int LOG2W, bool UP2, int BM>
+template <int LOG2W, bool UP2, int BM, int BN>
 static void launch_wgrad_p_cfg(const WgradArgsP& a, int blocks, hipStream_t st) {
   constexpr int W = 1 << LOG2W, NP = (64 >> LOG2W) * (W + 2), PXB = ((NP + 11) / 16) * 16 + 4;
-  constexpr size_t lds = (size_t)2 * (2 * (BM / 8) * 68 + 2 * (8192 / BM / 8) * PXB) * 16;
-  static_assert(lds <= 160 * 1024, "LDS");
-  auto kern = conv_wgrad_bf16p_kernel<LOG2W, UP2, BM>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
+  constexpr size_t lds = (size_t)2 * (2 * (BM / 8) * 68 + 2 * (BN / 8) * PXB) * 16;
+  if constexpr (lds <= 160 * 1024) {
+    auto kern = conv_wgrad_bf16p_kernel<LOG2W, UP2, BM, BN>;
+    static bool attr_set = false;
+    if (!attr_set) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(768), lds, st, a);
   }
-  hipLaunchKernelGGL(kern, dim3(blocks), dim3(768), lds, st, a);
 }
 template <int LOG2W>
-static void launch_wgrad_p(const WgradArgsP& a, int bm, int up2, int blocks, hipStream_t st) {
+static void launch_wgrad_p(const WgradArgsP& a, int bm, int bn, int up2, int blocks, hipStream_t st) {
   if (bm == 64) {
-    if (up2) launch_wgrad_p_cfg<LOG2W, true, 64>(a, blocks, st);
-    else launch_wgrad_p_cfg<LOG2W, false, 64>(a, blocks, st);
+    if (up2) launch_wgrad_p_cfg<LOG2W, true, 64, 128>(a, blocks, st);
+    else launch_wgrad_p_cfg<LOG2W, false, 64, 128>(a, blocks, st);
+  } else if (bn == 128) {
+    if (up2) launch_wgrad_p_cfg<LOG2W, true, 128, 128>(a, blocks, st);
+    else launch_wgrad_p_cfg<LOG2W, false, 128, 128>(a, blocks, st);
   } else {
-    if (up2) launch_wgrad_p_cfg<LOG2W, true, 128>(a, blocks, st);
-    else launch_wgrad_p_cfg<LOG2W, false, 128>(a, blocks, st);
+    if (up2) launch_wgrad_p_cfg<LOG2W, true, 128, 64>(a, blocks, st);
+    else launch_wgrad_p_cfg<LOG2W, false, 128, 64>(a, blocks, st);
   }
 }
 
@@ -2669,11 +2692,11 @@ int itcv_conv2d_wgrad_bf16p(const void* xplanes, const void* dyplanes, float* dw
   {
     ProfScope prof(st, 7, log2_exact(W), p.bm, up2 ? 1 : 0, 2, 2.0 * B * H * W * (double)Co * Ci * KS * KS);
     switch (log2_exact(W)) {
-      case 2: launch_wgrad_p<2>(a, p.bm, up2, blocks, st); break;
-      case 3: launch_wgrad_p<3>(a, p.bm, up2, blocks, st); break;
-      case 4: launch_wgrad_p<4>(a, p.bm, up2, blocks, st); break;
-      case 5: launch_wgrad_p<5>(a, p.bm, up2, blocks, st); break;
-      default: launch_wgrad_p<6>(a, p.bm, up2, blocks, st); break;
+      case 2: launch_wgrad_p<2>(a, p.bm, p.bn, up2, blocks, st); break;
+      case 3: launch_wgrad_p<3>(a, p.bm, p.bn, up2, blocks, st); break;
+      case 4: launch_wgrad_p<4>(a, p.bm, p.bn, up2, blocks, st); break;
+      case 5: launch_wgrad_p<5>(a, p.bm, p.bn, up2, blocks, st); break;
+      default: launch_wgrad_p<6>(a, p.bm, p.bn, up2, blocks, st); break;
     }
   }
   ITCV_CHECK_LAUNCH("itcv_conv2d_wgrad_bf16p");

@@ -23,7 +23,7 @@ def fold(name):
     m = re.search(r"conv_fwd_bf16p2_kernel<(\d+), (\d+), (true|false)>", name)
     if m:
         return f"conv_fwd_bf16p2_kernel<LOG2W={m[1]},BM={m[2]},up2={int(m[3] == 'true')},NS=2>"
-    m = re.search(r"conv_wgrad_bf16p_kernel<(\d+), (true|false), (\d+)>", name)
+    m = re.search(r"conv_wgrad_bf16p_kernel<(\d+), (true|false), (\d+)(?:, \d+)?>", name)
     if m:
         return f"conv_wgrad_bf16p_kernel<LOG2W={m[1]},BM={m[3]},up2={int(m[2] == 'true')},NS=2>"
     m = re.search(r"itcv::(\w+)(<[^(]*>)?\(", name)
