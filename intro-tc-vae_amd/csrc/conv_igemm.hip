@@ -1737,19 +1737,27 @@ __global__ __launch_bounds__(768) void conv_wgrad_bf16p_kernel(WgradArgsP a) {
   }
 }
 
-// dw[co][ci][tap] (+)= sum_s slab[s][tap][co][ci]   (one thread per (co, ci): coalesced slab reads, fixed order)
-__global__ void wgrad_p_reduce(const float* __restrict__ slab, float* __restrict__ dw, int CoCi, int splits,
-                               int accumulate) {
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < CoCi; i += gridDim.x * blockDim.x) {
-    float s[9];
+// dw[co][ci][tap] (+)= sum_s slab[s][tap][co][ci]: one thread per (tap, co, ci) -- slab reads coalesced along ci,
+// the slices summed in ascending order (fixed => bitwise reproducible), 8 loads in flight per thread so that the walk
+// over the slices is not one exposed memory round trip per slice.
+__global__ __launch_bounds__(256) void wgrad_p_reduce(const float* __restrict__ slab, float* __restrict__ dw, int CoCi,
+                                                     int splits, int accumulate) {
+  const size_t total = (size_t)CoCi * 9;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+    const int tp = (int)(idx / CoCi), e = (int)(idx - (size_t)tp * CoCi);
+    const float* p = slab + (size_t)tp * CoCi + e;
+    const size_t stride = (size_t)9 * CoCi;
+    float s = accumulate ? dw[(size_t)e * 9 + tp] : 0.f;
+    int k = 0;
+    for (; k + 8 <= splits; k += 8) {
+      float v[8];
 #pragma unroll
-    for (int tp = 0; tp < 9; ++tp) s[tp] = accumulate ? dw[(size_t)i * 9 + tp] : 0.f;
-    for (int k = 0; k < splits; ++k) {
+      for (int u = 0; u < 8; ++u) v[u] = p[(size_t)(k + u) * stride];
 #pragma unroll
-      for (int tp = 0; tp < 9; ++tp) s[tp] += slab[((size_t)k * 9 + tp) * CoCi + i];
+      for (int u = 0; u < 8; ++u) s += v[u];
     }
-#pragma unroll
-    for (int tp = 0; tp < 9; ++tp) dw[(size_t)i * 9 + tp] = s[tp];
+    for (; k < splits; ++k) s += p[(size_t)k * stride];
+    dw[(size_t)e * 9 + tp] = s;
   }
 }
 
@@ -2701,8 +2709,9 @@ int itcv_conv2d_wgrad_bf16p(const void* xplanes, const void* dyplanes, float* dw
   }
   ITCV_CHECK_LAUNCH("itcv_conv2d_wgrad_bf16p");
   const int coci = Co * Ci;
-  hipLaunchKernelGGL(wgrad_p_reduce, dim3(cdiv(coci, 256) < 2048 ? cdiv(coci, 256) : 2048), dim3(256), 0, st,
-                     static_cast<const float*>(ws), dw, coci, p.splits, accumulate);
+  const size_t rthreads = (size_t)coci * 9;
+  hipLaunchKernelGGL(wgrad_p_reduce, dim3((int)(cdivz(rthreads, 256) < 8192 ? cdivz(rthreads, 256) : 8192)), dim3(256), 0,
+                     st, static_cast<const float*>(ws), dw, coci, p.splits, accumulate);
   ITCV_CHECK_LAUNCH("itcv_conv2d_wgrad_bf16p(reduce)");
   return 0;
 }
