@@ -215,12 +215,31 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_fwd_kernel(ConvArgs a) {
 }
 
 // y[idx] = sum_s slab[s][idx] (+ bias[channel])
+// sum of the `splits` slabs at one element, ascending (fixed order), 8 loads in flight
+__device__ __forceinline__ float fold_slabs(const float* __restrict__ p, size_t stride, int splits) {
+  float s = 0.f;
+  int k = 0;
+  for (; k + 8 <= splits; k += 8) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = p[(size_t)(k + u) * stride];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s += v[u];
+  }
+  for (; k + 2 <= splits; k += 2) {
+    const float v0 = p[(size_t)k * stride], v1 = p[(size_t)(k + 1) * stride];
+    s += v0;
+    s += v1;
+  }
+  for (; k < splits; ++k) s += p[(size_t)k * stride];
+  return s;
+}
+
 __global__ void splitk_reduce_fwd(const float* __restrict__ slab, const float* __restrict__ bias,
                                   float* __restrict__ y, size_t total, size_t stride, int splits, int HW,
                                   int Co) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-    float s = 0.f;
-    for (int k = 0; k < splits; ++k) s += slab[(size_t)k * stride + i];
+    float s = fold_slabs(slab + i, stride, splits);
     if (bias) s += bias[(i / HW) % Co];
     y[i] = s;
   }
@@ -316,8 +335,7 @@ __global__ __launch_bounds__(256) void gemm64_kernel(GemmArgs a) {
 __global__ void gemm64_reduce(const float* __restrict__ slab, const float* __restrict__ bias, float* __restrict__ C,
                               size_t total, int N, int splits, int accumulate) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-    float s = 0.f;
-    for (int k = 0; k < splits; ++k) s += slab[(size_t)k * total + i];
+    float s = fold_slabs(slab + i, total, splits);
     if (bias) s += bias[i % N];
     C[i] = accumulate ? C[i] + s : s;
   }
