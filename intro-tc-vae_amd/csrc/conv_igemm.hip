@@ -215,31 +215,11 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_fwd_kernel(ConvArgs a) {
 }
 
 // y[idx] = sum_s slab[s][idx] (+ bias[channel])
-// sum of the `splits` slabs at one element, ascending (fixed order), 8 loads in flight
-__device__ __forceinline__ float fold_slabs(const float* __restrict__ p, size_t stride, int splits) {
-  float s = 0.f;
-  int k = 0;
-  for (; k + 8 <= splits; k += 8) {
-    float v[8];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) v[u] = p[(size_t)(k + u) * stride];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) s += v[u];
-  }
-  for (; k + 2 <= splits; k += 2) {
-    const float v0 = p[(size_t)k * stride], v1 = p[(size_t)(k + 1) * stride];
-    s += v0;
-    s += v1;
-  }
-  for (; k < splits; ++k) s += p[(size_t)k * stride];
-  return s;
-}
-
 __global__ void splitk_reduce_fwd(const float* __restrict__ slab, const float* __restrict__ bias,
                                   float* __restrict__ y, size_t total, size_t stride, int splits, int HW,
                                   int Co) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-    float s = fold_slabs(slab + i, stride, splits);
+    float s = fold_strided(0.f, slab + i, stride, splits);
     if (bias) s += bias[(i / HW) % Co];
     y[i] = s;
   }
@@ -335,7 +315,7 @@ __global__ __launch_bounds__(256) void gemm64_kernel(GemmArgs a) {
 __global__ void gemm64_reduce(const float* __restrict__ slab, const float* __restrict__ bias, float* __restrict__ C,
                               size_t total, int N, int splits, int accumulate) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-    float s = fold_slabs(slab + i, total, splits);
+    float s = fold_strided(0.f, slab + i, total, splits);
     if (bias) s += bias[i % N];
     C[i] = accumulate ? C[i] + s : s;
   }
@@ -1765,16 +1745,7 @@ __global__ __launch_bounds__(256) void wgrad_p_reduce(const float* __restrict__ 
     const int tp = (int)(idx / CoCi), e = (int)(idx - (size_t)tp * CoCi);
     const float* p = slab + (size_t)tp * CoCi + e;
     const size_t stride = (size_t)9 * CoCi;
-    float s = accumulate ? dw[(size_t)e * 9 + tp] : 0.f;
-    int k = 0;
-    for (; k + 8 <= splits; k += 8) {
-      float v[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] = p[(size_t)(k + u) * stride];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) s += v[u];
-    }
-    for (; k < splits; ++k) s += p[(size_t)k * stride];
+    const float s = fold_strided(accumulate ? dw[(size_t)e * 9 + tp] : 0.f, p, stride, splits);
     dw[(size_t)e * 9 + tp] = s;
   }
 }
@@ -1842,10 +1813,7 @@ __global__ void splitk_reduce_wgrad(const float* __restrict__ slab, float* __res
       const int tpb = 128 / cb;
       col = (tap / tpb) * 128 + (tap % tpb) * cb + ci;
     }
-    float s = accumulate ? dw[i] : 0.f;
-    const float* p = slab + (size_t)co * Np + col;
-    for (int k = 0; k < splits; ++k) s += p[(size_t)k * slab_stride];
-    dw[i] = s;
+    dw[i] = fold_strided(accumulate ? dw[i] : 0.f, slab + (size_t)co * Np + col, slab_stride, splits);
   }
 }
 
@@ -1869,8 +1837,7 @@ __global__ void bias_grad_combine(const double* __restrict__ part, float* __rest
                                   int accumulate) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
-  double s = 0.0;
-  for (int k = 0; k < splits; ++k) s += part[(size_t)k * C + c];
+  const double s = fold_strided(0.0, part + c, (size_t)C, splits);
   db[c] = (accumulate ? db[c] : 0.f) + (float)s;
 }
 

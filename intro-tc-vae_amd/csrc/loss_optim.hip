@@ -52,9 +52,7 @@ __global__ __launch_bounds__(256) void recon_partial_kernel(const float* __restr
 __global__ void recon_combine_kernel(const double* __restrict__ part, float* __restrict__ rows, int B, int splits) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= B) return;
-  double s = 0.0;
-  for (int k = 0; k < splits; ++k) s += part[(size_t)b * splits + k];
-  rows[b] = (float)s;
+  rows[b] = (float)fold_strided(0.0, part + (size_t)b * splits, (size_t)1, splits);
 }
 template <int LT>
 __global__ void recon_bwd_kernel(const float* __restrict__ x, const float* __restrict__ recon,

@@ -13,21 +13,6 @@ constexpr int kRedThreads = 256;
 // division by a runtime constant that is usually a power of two (sh = log2 or -1)
 __device__ __forceinline__ uint32_t fdiv(uint32_t a, uint32_t d, int sh) { return sh >= 0 ? (a >> sh) : (a / d); }
 
-// sum over the `splits` slices of one statistic, ascending (fixed order), with the loads of 8 slices in flight
-__device__ __forceinline__ double fold_slices(const double* __restrict__ p, size_t stride, int splits) {
-  double s = 0.0;
-  int k = 0;
-  for (; k + 8 <= splits; k += 8) {
-    double v[8];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) v[u] = p[(size_t)(k + u) * stride];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) s += v[u];
-  }
-  for (; k < splits; ++k) s += p[(size_t)k * stride];
-  return s;
-}
-
 // ------------------------------------------------------------------ channel moments (fp64)
 // grid (C, splits): block (c, s) reduces its slice of channel c's B*HW values
 struct BnFinal {   // arguments of the fused single-launch path (splits == 1)
@@ -90,9 +75,7 @@ __global__ __launch_bounds__(kRedThreads) void bn_moments_partial(const float* _
 __global__ void combine_partials(const double* __restrict__ part, double* __restrict__ sums, int C2, int splits) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= C2) return;
-  double s = 0.0;
-  for (int k = 0; k < splits; ++k) s += part[(size_t)k * C2 + i];
-  sums[i] = s;
+  sums[i] = fold_strided(0.0, part + i, (size_t)C2, splits);
 }
 
 __global__ void bn_finalize_kernel(const double* __restrict__ sums, double count, float eps, float momentum,
@@ -120,8 +103,8 @@ __global__ void bn_combine_finalize_kernel(const double* __restrict__ part, int 
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c == 0 && nbt) nbt[0] += 1;
   if (c >= C) return;
-  const double s1 = fold_slices(part + c, (size_t)2 * C, splits);
-  const double s2 = fold_slices(part + C + c, (size_t)2 * C, splits);
+  const double s1 = fold_strided(0.0, part + c, (size_t)2 * C, splits);
+  const double s2 = fold_strided(0.0, part + C + c, (size_t)2 * C, splits);
   const double m = s1 / count;
   double var = s2 / count - m * m;
   if (var < 0.0) var = 0.0;
@@ -139,8 +122,8 @@ __global__ void bn_combine_param_kernel(const double* __restrict__ part, double*
                                         int splits, float* dgamma, float* dbeta, int accumulate) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
-  const double s1 = fold_slices(part + c, (size_t)2 * C, splits);
-  const double s2 = fold_slices(part + C + c, (size_t)2 * C, splits);
+  const double s1 = fold_strided(0.0, part + c, (size_t)2 * C, splits);
+  const double s2 = fold_strided(0.0, part + C + c, (size_t)2 * C, splits);
   dsums[c] = s1;
   dsums[C + c] = s2;
   if (dbeta) dbeta[c] = (accumulate ? dbeta[c] : 0.f) + (float)s1;
@@ -242,8 +225,8 @@ __global__ __launch_bounds__(256) void bn_act_fwd_planes_kernel(
       const uint32_t last = min(base + blockDim.x, total) - 1, ng = last / per_plane - g0 + 1;
       if (threadIdx.x < ng * 8) {
         const uint32_t g = g0 + threadIdx.x / 8, c = (g % C8) * 8 + (threadIdx.x & 7);
-        const double s1 = fold_slices(st.part + c, (size_t)2 * C, st.splits);
-        const double s2 = fold_slices(st.part + C + c, (size_t)2 * C, st.splits);
+        const double s1 = fold_strided(0.0, st.part + c, (size_t)2 * C, st.splits);
+        const double s2 = fold_strided(0.0, st.part + C + c, (size_t)2 * C, st.splits);
         const double m = s1 / st.count;
         double var = s2 / st.count - m * m;
         if (var < 0.0) var = 0.0;
@@ -526,8 +509,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_planes(
       const uint32_t last = min(base + blockDim.x, total) - 1, ng = last / per_plane - g0 + 1;
       if (threadIdx.x < ng * 8) {
         const uint32_t g = g0 + threadIdx.x / 8, c = (g % C8) * 8 + (threadIdx.x & 7);
-        const double s1 = fold_slices(sm.part + c, (size_t)2 * C, sm.splits);
-        const double s2 = fold_slices(sm.part + C + c, (size_t)2 * C, sm.splits);
+        const double s1 = fold_strided(0.0, sm.part + c, (size_t)2 * C, sm.splits);
+        const double s2 = fold_strided(0.0, sm.part + C + c, (size_t)2 * C, sm.splits);
         s_m1[threadIdx.x] = (float)(s1 / count), s_m2[threadIdx.x] = (float)(s2 / count);
         if (g < C8 && g * per_plane >= base) {
           sm.dsums_out[c] = s1, sm.dsums_out[C + c] = s2;
