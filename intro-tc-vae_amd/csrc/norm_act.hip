@@ -35,6 +35,7 @@ __global__ __launch_bounds__(kRedThreads) void bn_moments_partial(const float* _
   const uint32_t beg = s * chunk, end = min(beg + chunk, total);
   double s1 = 0.0, s2 = 0.0;
   if ((HW & 3) == 0) {
+#pragma unroll 4
     for (uint32_t i = beg + threadIdx.x * 4; i < end; i += kRedThreads * 4) {
       const uint32_t b = fdiv(i, hw_n, hw_shift), hw = i - b * hw_n;
       const float4 v = *reinterpret_cast<const float4*>(x + ((size_t)b * C + c) * hw_n + hw);
@@ -410,6 +411,7 @@ __global__ __launch_bounds__(kRedThreads) void bn_bwd_partial_v4(
   const uint32_t beg = s * chunk, end = min(beg + chunk, total);
   const float mu = mean[c], rs = rstd[c], ga = gamma[c], be = beta[c];
   double s1 = 0.0, s2 = 0.0;
+#pragma unroll 2
   for (uint32_t i = beg + threadIdx.x * 4; i < end; i += kRedThreads * 4) {
     const uint32_t b = fdiv(i, HW, hw_shift), hw = i - b * HW;
     const uint32_t h = fdiv(hw, W, w_shift), w = hw - h * W;

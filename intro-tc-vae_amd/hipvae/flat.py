@@ -63,7 +63,7 @@ class FlatGroup:
         self.step += 1
         call("itcv_adam_step_dev", ptr(self.flat_p), ptr(self.flat_g), ptr(self.exp_avg), ptr(self.exp_avg_sq),
              self.numel, float(lr), float(betas[0]), float(betas[1]), float(eps), ptr(self.step_dev), stream())
-        bump_weight_epoch()          # parameters changed behind torch's back: drop packed-weight caches
+        bump_weight_epoch(self.params)   # these parameters changed behind torch's back: drop their packed copies
 
 
 def clip_grad_norm(groups, clip):

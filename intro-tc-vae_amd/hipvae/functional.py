@@ -96,10 +96,18 @@ _WEIGHT_EPOCH = [0]
 _PACK_CACHE = {}
 
 
-def bump_weight_epoch():
-    """Call after parameters were modified through raw pointers (fused Adam): invalidates the
-    packed-weight cache (torch's own in-place ops are tracked through ``tensor._version``)."""
-    _WEIGHT_EPOCH[0] += 1
+_PARAM_EPOCH = {}
+
+
+def bump_weight_epoch(params=None):
+    """Call after parameters were modified through raw pointers (fused Adam): invalidates the packed-weight
+    cache (torch's own in-place ops are tracked through ``tensor._version``).  ``params``: only these tensors
+    changed (the optimiser step of one model half leaves the other half's packed weights valid)."""
+    if params is None:
+        _WEIGHT_EPOCH[0] += 1
+        return
+    for p in params:
+        _PARAM_EPOCH[id(p)] = _PARAM_EPOCH.get(id(p), 0) + 1
 
 
 import os as _os
@@ -145,11 +153,12 @@ def conv_math_scope(mode):
 def packed_weight(weight, w4, for_dgrad, ns=0):
     """Packed operand of ``weight`` (viewed as ``w4`` [Co,Ci,KS,KS]), cached until the weight changes:
     the frozen half of the model is packed once per phase instead of once per network pass."""
-    key = (weight.data_ptr(), weight._version, _WEIGHT_EPOCH[0])
+    key = (weight.data_ptr(), weight._version, _WEIGHT_EPOCH[0], _PARAM_EPOCH.get(id(weight), 0))
     ent = _PACK_CACHE.get(id(weight))
     if ent is None:
         ent = _PACK_CACHE[id(weight)] = [key, {}]
         weakref.finalize(weight, _PACK_CACHE.pop, id(weight), None)
+        weakref.finalize(weight, _PARAM_EPOCH.pop, id(weight), None)
     elif ent[0] != key:
         ent[0], ent[1] = key, {}
     wp = ent[1].get((for_dgrad, ns))
