@@ -223,7 +223,7 @@ def main():
         "algorithmic_gflop_per_launch": round(dom[1] / dom[0] * 1e-9, 3),
         "all_conv_kernels": {"achieved": round(conv_flop / conv_time * 1e-12, 2),
                              "share_of_eager_step_time": round(conv_time / eager_elapsed, 3)},
-        "measured": f"HIP event pairs recorded inside libitcv_hip.so on the launch stream around every main conv kernel during {args.steps} eager steps of this workload, same process"
+        "measured": f"HIP event pairs stamped at kernel start/end (hipExtLaunchKernelGGL inside libitcv_hip.so, launch stream) for every main conv kernel during {args.steps} eager steps of this workload, same process; they include the end-of-kernel L2 write-back of the result (about output bytes / 5 TB/s), which rocprofv3's dispatch timestamps in profiles/r01_final_kernel_stats.csv do not (5-20 % shorter there)"
                     + (", immediately before the timed hipGraph-replay steps" if use_graph else " (the timed region)"),
     }
 

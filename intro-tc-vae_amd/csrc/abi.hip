@@ -20,13 +20,19 @@ ProfScope::ProfScope(hipStream_t stream, int kind, int ks, int bm, int up2, int 
   r.code = kind | (ks << 4) | (bm << 8) | (up2 << 16) | (ns << 20);
   r.flop = flop;
   if (hipEventCreate(&r.start) != hipSuccess || hipEventCreate(&r.stop) != hipSuccess) return;
-  (void)hipEventRecord(r.start, st);
   g_prof.push_back(r);
   slot = (int)g_prof.size() - 1;
+  g_prof_start = r.start, g_prof_stop = r.stop;   // consumed by the scope's launch_timed()
 }
 ProfScope::~ProfScope() {
-  if (slot >= 0) (void)hipEventRecord(g_prof[slot].stop, st);
+  if (slot >= 0 && g_prof_start) {   // nothing was launched through launch_timed(): drop the record
+    (void)hipEventDestroy(g_prof[slot].start);
+    (void)hipEventDestroy(g_prof[slot].stop);
+    g_prof.pop_back();
+  }
+  g_prof_start = g_prof_stop = nullptr;
 }
+thread_local hipEvent_t g_prof_start = nullptr, g_prof_stop = nullptr;
 }
 
 extern "C" {

@@ -1,6 +1,7 @@
 // Shared helpers for libitcv_hip.so (gfx950 only).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
@@ -127,5 +128,20 @@ struct ProfScope {
   ProfScope(hipStream_t stream, int kind, int ks, int bm, int up2, int ns, double flop);
   ~ProfScope();
 };
+// Event pair of the innermost live ProfScope (null when not profiling).  launch_timed() hands it to
+// hipExtLaunchKernelGGL, which stamps the events at the kernel's own start and end: the record is the kernel's
+// execution time (what rocprofv3 reports), free of the dispatch latency a hipEventRecord pair would include
+// whenever the stream runs dry.
+extern thread_local hipEvent_t g_prof_start, g_prof_stop;
+
+template <typename K, typename... Args>
+inline void launch_timed(K kernel, dim3 grid, dim3 block, size_t lds, hipStream_t st, Args... args) {
+  if (g_prof_start) {
+    hipExtLaunchKernelGGL(kernel, grid, block, lds, st, g_prof_start, g_prof_stop, 0, args...);
+    g_prof_start = nullptr;   // one kernel per scope: a second launch in the same scope is not part of the record
+  } else {
+    hipLaunchKernelGGL(kernel, grid, block, lds, st, args...);
+  }
+}
 
 }  // namespace itcv

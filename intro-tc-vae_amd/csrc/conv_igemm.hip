@@ -1914,13 +1914,13 @@ static void launch_fwd_cfg(const ConvArgs& a, int splits, int up2, hipStream_t s
   dim3 grid(cdiv(a.nt, 8) * 8 * a.mt, splits), block(WM * WN * 64);
   const bool tail = (a.Ci & 15) != 0;
   if (up2 && tail)
-    hipLaunchKernelGGL((conv_fwd_kernel<KS, BM, BN, WM, WN, true, true>), grid, block, 0, st, a);
+    launch_timed((conv_fwd_kernel<KS, BM, BN, WM, WN, true, true>), grid, block, 0, st, a);
   else if (up2)
-    hipLaunchKernelGGL((conv_fwd_kernel<KS, BM, BN, WM, WN, true, false>), grid, block, 0, st, a);
+    launch_timed((conv_fwd_kernel<KS, BM, BN, WM, WN, true, false>), grid, block, 0, st, a);
   else if (tail)
-    hipLaunchKernelGGL((conv_fwd_kernel<KS, BM, BN, WM, WN, false, true>), grid, block, 0, st, a);
+    launch_timed((conv_fwd_kernel<KS, BM, BN, WM, WN, false, true>), grid, block, 0, st, a);
   else
-    hipLaunchKernelGGL((conv_fwd_kernel<KS, BM, BN, WM, WN, false, false>), grid, block, 0, st, a);
+    launch_timed((conv_fwd_kernel<KS, BM, BN, WM, WN, false, false>), grid, block, 0, st, a);
 }
 
 template <int KS>
@@ -1937,11 +1937,11 @@ template <int KS, int CB, bool UP2>
 static void launch_wgrad_bm(const WgradArgs& a, int bm, hipStream_t st) {
   dim3 grid(cdiv(a.splits, 8) * 8 * a.tiles);
   if (bm == 32)
-    hipLaunchKernelGGL((conv_wgrad_kernel<KS, 32, CB, 1, 4, UP2, 1>), grid, dim3(256), 0, st, a);
+    launch_timed((conv_wgrad_kernel<KS, 32, CB, 1, 4, UP2, 1>), grid, dim3(256), 0, st, a);
   else if (bm == 64)
-    hipLaunchKernelGGL((conv_wgrad_kernel<KS, 64, CB, 1, 4, UP2, 1>), grid, dim3(256), 0, st, a);
+    launch_timed((conv_wgrad_kernel<KS, 64, CB, 1, 4, UP2, 1>), grid, dim3(256), 0, st, a);
   else
-    hipLaunchKernelGGL((conv_wgrad_kernel<KS, 128, CB, 2, 2, UP2, 1>), grid, dim3(256), 0, st, a);
+    launch_timed((conv_wgrad_kernel<KS, 128, CB, 2, 2, UP2, 1>), grid, dim3(256), 0, st, a);
 }
 template <int KS, bool UP2>
 static void launch_wgrad_cb(const WgradArgs& a, int bm, int cb, hipStream_t st) {
@@ -2006,20 +2006,20 @@ static void launch_fwd_b(const ConvArgsB& a, int bm, int splits, int up2, hipStr
   if (bf16s_ws()) {
     dim3 blk(512);
     if (bm == 64) {
-      if (up2) hipLaunchKernelGGL((conv_fwd_bf16s_ws_kernel<KS, 64, 256, 1, 4, true, NS>), grid, blk, 0, st, a);
-      else hipLaunchKernelGGL((conv_fwd_bf16s_ws_kernel<KS, 64, 256, 1, 4, false, NS>), grid, blk, 0, st, a);
+      if (up2) launch_timed((conv_fwd_bf16s_ws_kernel<KS, 64, 256, 1, 4, true, NS>), grid, blk, 0, st, a);
+      else launch_timed((conv_fwd_bf16s_ws_kernel<KS, 64, 256, 1, 4, false, NS>), grid, blk, 0, st, a);
     } else {
-      if (up2) hipLaunchKernelGGL((conv_fwd_bf16s_ws_kernel<KS, 128, 128, 2, 2, true, NS>), grid, blk, 0, st, a);
-      else hipLaunchKernelGGL((conv_fwd_bf16s_ws_kernel<KS, 128, 128, 2, 2, false, NS>), grid, blk, 0, st, a);
+      if (up2) launch_timed((conv_fwd_bf16s_ws_kernel<KS, 128, 128, 2, 2, true, NS>), grid, blk, 0, st, a);
+      else launch_timed((conv_fwd_bf16s_ws_kernel<KS, 128, 128, 2, 2, false, NS>), grid, blk, 0, st, a);
     }
     return;
   }
   if (bm == 64) {
-    if (up2) hipLaunchKernelGGL((conv_fwd_bf16s_kernel<KS, 64, 256, 1, 4, true, NS>), grid, block, 0, st, a);
-    else hipLaunchKernelGGL((conv_fwd_bf16s_kernel<KS, 64, 256, 1, 4, false, NS>), grid, block, 0, st, a);
+    if (up2) launch_timed((conv_fwd_bf16s_kernel<KS, 64, 256, 1, 4, true, NS>), grid, block, 0, st, a);
+    else launch_timed((conv_fwd_bf16s_kernel<KS, 64, 256, 1, 4, false, NS>), grid, block, 0, st, a);
   } else {
-    if (up2) hipLaunchKernelGGL((conv_fwd_bf16s_kernel<KS, 128, 128, 2, 2, true, NS>), grid, block, 0, st, a);
-    else hipLaunchKernelGGL((conv_fwd_bf16s_kernel<KS, 128, 128, 2, 2, false, NS>), grid, block, 0, st, a);
+    if (up2) launch_timed((conv_fwd_bf16s_kernel<KS, 128, 128, 2, 2, true, NS>), grid, block, 0, st, a);
+    else launch_timed((conv_fwd_bf16s_kernel<KS, 128, 128, 2, 2, false, NS>), grid, block, 0, st, a);
   }
 }
 
@@ -2043,7 +2043,7 @@ static void launch_fwd_p_cfg(const ConvArgsP& a, int splits, hipStream_t st) {
     attr_set = true;
   }
   dim3 grid(cdiv(a.nt, 8) * 8 * a.mt, splits), blk(512);
-  hipLaunchKernelGGL(kern, grid, blk, lds, st, a);
+  launch_timed(kern, grid, blk, lds, st, a);
 }
 template <int KS, int NS, int NSTAGE>
 static void launch_fwd_p_st(const ConvArgsP& a, int bm, int splits, int up2, hipStream_t st) {
@@ -2132,7 +2132,7 @@ static void launch_fwd_p2_cfg(const ConvArgsP2& a, int splits, size_t lds, hipSt
     attr = lds;
   }
   dim3 grid(cdiv(a.nt, 8) * 8 * a.mt, splits);
-  hipLaunchKernelGGL(kern, grid, dim3(768), lds, st, a);
+  launch_timed(kern, grid, dim3(768), lds, st, a);
 }
 template <int LOG2W>
 static void launch_fwd_p2_w(const ConvArgsP2& a, int bm, int up2, int splits, size_t lds, hipStream_t st) {
@@ -2185,7 +2185,7 @@ static void launch_wgrad_p_cfg(const WgradArgsP& a, int blocks, hipStream_t st) 
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       attr_set = true;
     }
-    hipLaunchKernelGGL(kern, dim3(blocks), dim3(768), lds, st, a);
+    launch_timed(kern, dim3(blocks), dim3(768), lds, st, a);
   }
 }
 template <int LOG2W>
@@ -2206,9 +2206,9 @@ template <int KS, int CB, int NS>
 static void launch_wgrad_b_bm(const WgradArgs& a, int bm, hipStream_t st) {
   dim3 grid(cdiv(a.splits, 8) * 8 * a.tiles);
   if (bm == 64)
-    hipLaunchKernelGGL((conv_wgrad_bf16s_kernel<KS, 64, CB, 1, 4, NS>), grid, dim3(256), 0, st, a);
+    launch_timed((conv_wgrad_bf16s_kernel<KS, 64, CB, 1, 4, NS>), grid, dim3(256), 0, st, a);
   else
-    hipLaunchKernelGGL((conv_wgrad_bf16s_kernel<KS, 128, CB, 2, 2, NS>), grid, dim3(256), 0, st, a);
+    launch_timed((conv_wgrad_bf16s_kernel<KS, 128, CB, 2, 2, NS>), grid, dim3(256), 0, st, a);
 }
 template <int KS, int NS>
 static void launch_wgrad_b(const WgradArgs& a, int bm, int cb, hipStream_t st) {

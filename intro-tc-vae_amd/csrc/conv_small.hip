@@ -141,10 +141,10 @@ int itcv_conv2d_small_cout_fwd(const float* x, const float* w, const float* bias
 #define ITCV_SMALL(KS_, CO_)                                                                                       \
   do {                                                                                                             \
     if (for_dgrad)                                                                                                 \
-      hipLaunchKernelGGL((conv_small_cout_kernel<KS_, CO_, true>), grid, block, 0, st, x, w, bias, y, C, H, W, Cw, \
+      launch_timed((conv_small_cout_kernel<KS_, CO_, true>), grid, block, 0, st, x, w, bias, y, C, H, W, Cw, \
                          tx, ty);                                                                                  \
     else                                                                                                           \
-      hipLaunchKernelGGL((conv_small_cout_kernel<KS_, CO_, false>), grid, block, 0, st, x, w, bias, y, C, H, W,    \
+      launch_timed((conv_small_cout_kernel<KS_, CO_, false>), grid, block, 0, st, x, w, bias, y, C, H, W,    \
                          Cw, tx, ty);                                                                              \
   } while (0)
 #define ITCV_SMALL_KS(KS_)                    \
@@ -182,10 +182,10 @@ int itcv_conv2d_small_cin_fwd(const float* x, const float* w, const float* bias,
 #define ITCV_SCIN(KS_, CI_)                                                                                      \
   do {                                                                                                           \
     if (for_dgrad)                                                                                               \
-      hipLaunchKernelGGL((conv_small_cin_kernel<KS_, CI_, true>), grid, block, 0, st, x, w, bias, y, Co, H, W, tx, \
+      launch_timed((conv_small_cin_kernel<KS_, CI_, true>), grid, block, 0, st, x, w, bias, y, Co, H, W, tx, \
                          ty);                                                                                    \
     else                                                                                                         \
-      hipLaunchKernelGGL((conv_small_cin_kernel<KS_, CI_, false>), grid, block, 0, st, x, w, bias, y, Co, H, W,  \
+      launch_timed((conv_small_cin_kernel<KS_, CI_, false>), grid, block, 0, st, x, w, bias, y, Co, H, W,  \
                          tx, ty);                                                                                \
   } while (0)
 #define ITCV_SCIN_KS(KS_)                 \
