@@ -1,0 +1,133 @@
+"""GPU tests of the pre-split "planes" pipeline (include/itcv_hip.h: itcv_split_planes, itcv_conv2d_fwd_bf16p,
+itcv_conv2d_wgrad_bf16p, itcv_bn_train_fwd / _bwd with planes): the operand format of the split-bf16 hot GEMMs.
+
+* planes reconstruct the tensor (2^-16 relative with two bf16 planes, fp32-exact class with three);
+* the LDS-DMA kernels on planes give BIT-IDENTICAL results to the gather kernels on the fp32 tensor where the
+  K decomposition is the same (no split-K), and agree to rounding where it differs;
+* the transposing-read weight gradient against an fp64 reference (5e-5 of the result scale in bf16x3);
+* BatchNorm passes that emit planes (and fold their statistics in the apply launch) against an fp64 reference,
+  with the planes equal to a split of the fp32 output.
+"""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def HF():
+    from hipvae import functional
+    return functional
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def rel_err(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+def unpack_planes(xp, shape, ns):
+    """planes [ns][B][C/8][H*W] x 8 bf16 -> fp32 [B,C,H,W] (sum of the planes)."""
+    B, C, H, W = shape
+    raw = xp.view(torch.int16).view(ns, B, C // 8, H * W, 8)                 # bf16 bit patterns
+    vals = (raw.to(torch.int32) << 16).view(torch.float32)                  # bf16 -> fp32 is a 16-bit shift
+    return vals.sum(0).permute(0, 1, 3, 2).reshape(B, C, H, W)
+
+
+@pytest.mark.parametrize("ns,tol", [(2, 2.0 ** -15), (3, 2.0 ** -22)])
+def test_split_planes_reconstructs(HF, ns, tol):
+    g = torch.Generator().manual_seed(11)
+    x = (torch.randn(3, 16, 8, 12, generator=g) * torch.logspace(-3, 3, 16).view(1, 16, 1, 1)).to(dev())
+    xp = HF.split_planes(x, ns)
+    back = unpack_planes(xp, x.shape, ns)
+    assert float(((back - x).abs() / x.abs().clamp_min(1e-30)).max()) < tol
+
+
+PLANES_CASES = [  # B, Ci, H, W, Co, up2 -- band kernel (W in 8..64), 128-pixel-tile kernel (W = 4), 64- and 128-row tiles
+    (2, 64, 16, 16, 64, False), (2, 128, 8, 8, 160, False), (3, 32, 32, 32, 48, False), (2, 64, 64, 64, 64, False),
+    (4, 128, 4, 4, 256, False), (2, 64, 16, 16, 128, True), (2, 96, 32, 32, 64, True),
+]
+
+
+@pytest.mark.parametrize("case", PLANES_CASES)
+@pytest.mark.parametrize("mode", ["bf16x3", "bf16x6"])
+def test_planes_conv_equals_gather_conv(HF, mode, case):
+    """Forward and data-gradient on planes vs the kernels that gather + split the fp32 tensor themselves."""
+    B, Ci, H, W, Co, up2 = case
+    ns = 2 if mode == "bf16x3" else 3
+    g = torch.Generator().manual_seed(sum(case[:5]))
+    hs, ws = (H // 2, W // 2) if up2 else (H, W)
+    x = torch.randn(B, Ci, hs, ws, generator=g).to(dev())
+    w = (torch.randn(Co, Ci, 3, 3, generator=g) / (Ci * 9) ** 0.5).to(dev())
+    dy = torch.randn(B, Co, H, W, generator=g).to(dev())
+    with HF.conv_math_scope(mode):
+        ref = HF.conv_apply(x, w, w, 0, None, B, Ci, H, W, Co, 3, up2)
+        got = HF.conv_apply_planes(HF.split_planes(x, ns), w, w, 0, None, B, Ci, H, W, Co, 3, up2, ns)
+        pairs = [(got, ref)]
+        if HF.lib.itcv_conv2d_bf16s_supported(Co, Ci, 3):   # data-gradient: the channel roles swap
+            refd = HF.conv_apply(dy, w, w, 1, None, B, Co, H, W, Ci, 3, False)
+            gotd = HF.conv_apply_planes(HF.split_planes(dy, ns), w, w, 1, None, B, Co, H, W, Ci, 3, False, ns)
+            pairs.append((gotd, refd))
+    for a, b in pairs:
+        assert torch.equal(a, b) or rel_err(a, b) < 2e-6   # equal unless the two kernels split K differently
+
+
+WGRAD_CASES = [  # B, Ci, H, W, Co, up2
+    (2, 64, 16, 16, 64, False), (4, 128, 4, 4, 256, False), (2, 32, 32, 32, 48, False), (1, 64, 64, 64, 64, False),
+    (2, 128, 16, 16, 64, True), (2, 512, 8, 8, 256, False), (8, 24, 8, 8, 136, False),
+]
+
+
+@pytest.mark.parametrize("case", WGRAD_CASES)
+def test_planes_weight_gradient(HF, case):
+    B, Ci, H, W, Co, up2 = case
+    assert HF.lib.itcv_conv2d_wgrad_bf16p_supported(B, Ci, H, W, Co, 3)
+    g = torch.Generator().manual_seed(7 + sum(case[:5]))
+    hs, ws = (H // 2, W // 2) if up2 else (H, W)
+    x = torch.randn(B, Ci, hs, ws, generator=g)
+    dy = torch.randn(B, Co, H, W, generator=g)
+    xin = F.interpolate(x.double(), scale_factor=2, mode="nearest") if up2 else x.double()
+    ref = torch.nn.grad.conv2d_weight(xin, (Co, Ci, 3, 3), dy.double(), padding=1)
+    xp, dyp = HF.split_planes(x.to(dev()), 2), HF.split_planes(dy.to(dev()), 2)
+    dw = HF.conv_wgrad_planes(xp, dyp, B, Ci, H, W, Co, 3, up2)
+    assert rel_err(dw, ref) < 5e-5
+    acc = HF.conv_wgrad_planes(xp, dyp, B, Ci, H, W, Co, 3, up2, out=dw.clone(), accumulate=True)
+    assert rel_err(acc, 2 * ref) < 5e-5
+    again = HF.conv_wgrad_planes(xp, dyp, B, Ci, H, W, Co, 3, up2)
+    assert torch.equal(dw, again)   # split-K slabs are reduced in a fixed order
+
+
+@pytest.mark.parametrize("shape,pool", [((4, 64, 32, 32), False), ((4, 64, 32, 32), True), ((2, 16, 8, 8), False),
+                                        ((8, 128, 16, 16), False)])
+def test_batchnorm_emits_planes(HF, shape, pool):
+    """BnActFn with planes outputs (statistics folded into the apply launch where the reduction is sliced)."""
+    B, C, H, W = shape
+    g = torch.Generator().manual_seed(B + C + H)
+    x = torch.randn(B, C, H, W, generator=g) * 1.5 + 0.3
+    gamma, beta = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g)
+    oshape = (B, C, H // 2, W // 2) if pool else shape
+    dy = torch.randn(*oshape, generator=g)
+    xr, gr, br = (t.double().requires_grad_(True) for t in (x, gamma, beta))
+    yr = F.leaky_relu(F.batch_norm(xr, None, None, gr, br, True, 0.1, 1e-4), 0.2)
+    yr = F.avg_pool2d(yr, 2) if pool else yr
+    yr.backward(dy.double())
+    xd, gd, bd = (t.to(dev()).requires_grad_(True) for t in (x, gamma, beta))
+    rm, rv = torch.zeros(C, device=dev()), torch.ones(C, device=dev())
+    nbt = torch.zeros((), dtype=torch.int64, device=dev())
+    y = HF.BnActFn.apply(xd, gd, bd, None, rm, rv, nbt, 1e-4, 0.1, 0.2, pool, True, None, 2, 2, True, True)
+    assert rel_err(y, yr) < 1e-5
+    yp = HF._tagged_planes(y, 2)
+    assert yp is not None and torch.equal(yp, HF.split_planes(y.detach(), 2))
+    y.backward(dy.to(dev()))
+    assert rel_err(xd.grad, xr.grad) < 2e-5 and rel_err(gd.grad, gr.grad) < 1e-5 and rel_err(bd.grad, br.grad) < 1e-5
+    mean_ref = x.double().mean((0, 2, 3))
+    assert rel_err(rm, 0.1 * mean_ref) < 1e-5 and int(nbt) == 1
+    # planes-only form: the fp32 tensors are not written, the planes still carry the same values
+    xd2 = x.to(dev()).requires_grad_(True)
+    y2 = HF.BnActFn.apply(xd2, gd.detach(), bd.detach(), None, rm.clone(), rv.clone(), nbt.clone(), 1e-4, 0.1, 0.2, pool,
+                          True, None, 2, 0, False, True)
+    assert torch.equal(HF._tagged_planes(y2, 2), yp)
