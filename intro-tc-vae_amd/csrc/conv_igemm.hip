@@ -1004,7 +1004,10 @@ __global__ __launch_bounds__(768) void conv_fwd_bf16p2_kernel(ConvArgsP2 a) {
   constexpr int WM = BM / 64, WN = 8 / WM, WTN = BN / WN, TM = 2, TN = WTN / 32;   // 128: 2x4 waves of 64x64; 64: 1x8 of 64x32
   constexpr int ASZ = NS * KC * BM;                // chunks per weight tile
   constexpr int PA = NS * KC * BM / 64 / 4;        // weight pieces per loader wave per K-tile
-  extern __shared__ u32x4 smem[];                  // [3][ASZ] weight ring, then [2][NS*KC*PXB] bands
+  // G K-tiles (taps) per barrier: the 64-row tiles do half the MFMA work per K-tile, so they take two taps per
+  // stage (the block-wide barrier and the LDS latency behind it were ~40 % of their K-tile time)
+  constexpr int G = BM == 64 ? 2 : 1, NSTG = (9 + G - 1) / G;
+  extern __shared__ u32x4 smem[];                  // [3][G][ASZ] weight ring, then [2][NS*KC*PXB] bands
 
   const int t = threadIdx.x, lane = t & 63;
   const int wid = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -1019,7 +1022,7 @@ __global__ __launch_bounds__(768) void conv_fwd_bf16p2_kernel(ConvArgsP2 a) {
   const int H = a.H, HW = H << LOG2W;
   const int PXB = a.PXB, BSZ = NS * KC * PXB;
   const uint32_t smem_base = lds_addr(smem);
-  const uint32_t band_base = smem_base + 3u * ASZ * 16u;
+  const uint32_t band_base = smem_base + 3u * G * ASZ * 16u;
 
   if (wid >= 8) {
     // ------------------------------------------------------------------ loaders
@@ -1062,25 +1065,48 @@ __global__ __launch_bounds__(768) void conv_fwd_bf16p2_kernel(ConvArgsP2 a) {
         lds_dma16(wt + (size_t)pk * a.Mp + mlc * 64, sbase + (uint32_t)(pk * BM + mlc * 64) * 16u);
       }
     };
+    // weight tiles of one stage (taps st*G .. of group cib) -> ring slot `slot`; past the end of the slice the last
+    // K-tile is fetched again (same instruction count: the counted waits stay valid)
+    auto issue_stage_A = [&](int cib, int st, int slot) {
+#pragma unroll
+      for (int u = 0; u < G; ++u)
+        if (st * G + u < 9) issue_A(min((cib - c0) * 9 + st * G + u, nk - 1), slot * G + u);
+    };
+    auto stage_taps = [](int st) { return (st * G + G <= 9) ? G : 9 - st * G; };
 #pragma unroll
     for (int qq = 0; qq < 8; ++qq)
       if (qq < a.NPC) issue_band_piece(c0, 0, soff[qq], (vmask >> qq) & 1u, qq);
-    issue_A(0, 0);
-    issue_A(min(1, nk - 1), 1);
-    wait_vmcnt<PA>();                                    // band and tile 0 landed; tile 1 may be in flight
+    issue_stage_A(c0, 0, 0);
+    issue_stage_A(c0, 1, 1);
+    wait_vmcnt<PA * (NSTG > 1 ? ((1 * G + G <= 9) ? G : 9 - G) : 0)>();   // band and stage 0 landed; stage 1 may be in flight
     __builtin_amdgcn_s_barrier();
-    int buf = 0;
+    int buf = 0, slot = 2;
     for (int cib = c0; cib < c1; ++cib) {
-      const int ib = (cib - c0) * 9;
 #pragma unroll
-      for (int tap = 0; tap < 9; ++tap) {
-        issue_A(min(ib + tap + 2, nk - 1), (tap + 2) % 3);   // into the slot K-tile i-1 has just left
-        // next group's band, one piece (x 2 planes) per tap
-        if (tap < 8 && tap < a.NPC && cib + 1 < c1) {
-          issue_band_piece(cib + 1, buf ^ 1, soff[tap < 8 ? tap : 0], (vmask >> tap) & 1u, tap);
-          wait_vmcnt<PA + NS>();                           // K-tile i+1's weights (and everything older) have landed
+      for (int st = 0; st < NSTG; ++st) {
+        const int st2 = (st + 2) % NSTG, cib2 = cib + (st + 2) / NSTG;
+        issue_stage_A(cib2, st2, slot);                       // into the slot stage S-1 has just left
+        if (++slot == 3) slot = 0;
+        // next group's band, one piece (x 2 planes) per tap of this stage
+        int nb = 0;
+#pragma unroll
+        for (int u = 0; u < G; ++u) {
+          const int tap = st * G + u;
+          if (tap < 8 && tap < a.NPC && cib + 1 < c1) {
+            issue_band_piece(cib + 1, buf ^ 1, soff[tap < 8 ? tap : 0], (vmask >> tap) & 1u, tap);
+            ++nb;
+          }
+        }
+        // stage S+1's weights (and everything older) have landed: only this iteration's loads may be in flight
+        const int na = stage_taps(st2);
+        if (na == G) {
+          if (nb == 0) wait_vmcnt<PA * G>();
+          else if (nb == 1) wait_vmcnt<PA * G + NS>();
+          else wait_vmcnt<PA * G + 2 * NS>();
         } else {
-          wait_vmcnt<PA>();
+          if (nb == 0) wait_vmcnt<PA*(9 % G ? 9 % G : G)>();
+          else if (nb == 1) wait_vmcnt<PA*(9 % G ? 9 % G : G) + NS>();
+          else wait_vmcnt<PA*(9 % G ? 9 % G : G) + 2 * NS>();
         }
         __builtin_amdgcn_s_barrier();
       }
@@ -1111,38 +1137,45 @@ __global__ __launch_bounds__(768) void conv_fwd_bf16p2_kernel(ConvArgsP2 a) {
   __builtin_amdgcn_s_barrier();
   int buf = 0;
   const long long dbg_c0 = a.debug ? clock64() : 0, dbg_w0 = a.debug ? wall_clock64() : 0;
+  int slot = 0;
   for (int cib = c0; cib < c1; ++cib) {
     const uint32_t bb = band_base + (uint32_t)(buf * BSZ) * 16u;
 #pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
-      const int tapoff = ((tap / 3 - 1) * WP + (tap % 3 - 1)) * 16;
-      const uint32_t ab = smem_base + (uint32_t)((tap % 3) * ASZ) * 16u + aoff;
+    for (int st = 0; st < NSTG; ++st) {
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        const int kc = ks * 2 + half;
-        bf16x8 af[NS][TM], bfr[NS][TN];
+      for (int u = 0; u < G; ++u) {
+        const int tap = st * G + u;
+        if (tap >= 9) continue;
+        const int tapoff = ((tap / 3 - 1) * WP + (tap % 3 - 1)) * 16;
+        const uint32_t ab = smem_base + (uint32_t)((slot * G + u) * ASZ) * 16u + aoff;
 #pragma unroll
-        for (int pp = 0; pp < NS; ++pp) {
+        for (int ks = 0; ks < 2; ++ks) {
+          const int kc = ks * 2 + half;
+          bf16x8 af[NS][TM], bfr[NS][TN];
+#pragma unroll
+          for (int pp = 0; pp < NS; ++pp) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+              af[pp][i] = __builtin_bit_cast(
+                  bf16x8, *(const __attribute__((address_space(3))) u32x4*)(size_t)(ab + (uint32_t)(((pp * KC + kc) * BM + i * 32) * 16)));
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+              bfr[pp][j] = __builtin_bit_cast(
+                  bf16x8, *(const __attribute__((address_space(3))) u32x4*)(size_t)(bb + (uint32_t)((pp * KC + kc) * PXB) * 16u + hoff[j] + tapoff));
+          }
 #pragma unroll
           for (int i = 0; i < TM; ++i)
-            af[pp][i] = __builtin_bit_cast(
-                bf16x8, *(const __attribute__((address_space(3))) u32x4*)(size_t)(ab + (uint32_t)(((pp * KC + kc) * BM + i * 32) * 16)));
 #pragma unroll
-          for (int j = 0; j < TN; ++j)
-            bfr[pp][j] = __builtin_bit_cast(
-                bf16x8, *(const __attribute__((address_space(3))) u32x4*)(size_t)(bb + (uint32_t)((pp * KC + kc) * PXB) * 16u + hoff[j] + tapoff));
+            for (int j = 0; j < TN; ++j) {
+              f32x16 c = acc[i][j];
+              c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bfr[1][j], c, 0, 0, 0);
+              c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][i], bfr[0][j], c, 0, 0, 0);
+              c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bfr[0][j], c, 0, 0, 0);
+              acc[i][j] = c;
+            }
         }
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-          for (int j = 0; j < TN; ++j) {
-            f32x16 c = acc[i][j];
-            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bfr[1][j], c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][i], bfr[0][j], c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bfr[0][j], c, 0, 0, 0);
-            acc[i][j] = c;
-          }
       }
+      if (++slot == 3) slot = 0;
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
     }
@@ -2100,7 +2133,7 @@ static FwdPlanP2 plan_fwd_p2(int B, int Ci, int H, int W, int Co, int KS, int ns
   p.bm = Co <= 64 ? 64 : 128;
   // mid-sized layers: 64-row tiles when that fills the chip without split-K and 128-row tiles would not
   if (p.bm == 128 && cdiv(Co, 128) * p.nt < 192 && cdiv(Co, 64) * p.nt >= 192 && p2_bm64_mid()) p.bm = 64;
-  p.lds = ((size_t)3 * 2 * 4 * p.bm + (size_t)2 * 2 * 4 * p.PXB) * 16;
+  p.lds = ((size_t)3 * (p.bm == 64 ? 2 : 1) * 2 * 4 * p.bm + (size_t)2 * 2 * 4 * p.PXB) * 16;   // [3][G] weight ring + 2 bands
   if (p.lds > 160 * 1024) return p;
   p.mt = cdiv(Co, p.bm);
   p.cpt = Ci / 32;
