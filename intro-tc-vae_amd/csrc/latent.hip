@@ -46,8 +46,12 @@ __device__ __forceinline__ float logdens(float d, float lv) {
 // One block per local row j.  dynamic LDS: spart[nwaves][Bt]
 // The estimator kernels walk the B_total rows of mu serially per latent column; straight from global memory every
 // step of that walk is an exposed L2 round trip (~0.7 us: 47 us for a 64 x 128 problem).  The rows are therefore
-// staged through LDS kTcChunk at a time (coalesced, once per pass); the arithmetic and its order are unchanged.
-constexpr int kTcChunk = 32;
+// staged through LDS tc_chunk(D) (<= 32) at a time (coalesced, once per pass); the arithmetic and its order are unchanged.
+constexpr int kTcChunkMax = 32;
+__host__ __device__ inline int tc_chunk(int D) {   // rows staged per pass: <= 32 and <= 32 KB per array
+  const int r = 8192 / (D > 0 ? D : 1);
+  return r < 1 ? 1 : (r > kTcChunkMax ? kTcChunkMax : r);
+}
 __device__ __forceinline__ void tc_stage_rows(float* dst, const float* __restrict__ src, int row0, int rows, int D) {
   const int n = rows * D;   // rows are contiguous in memory: one flat copy
   const float* s0 = src + (size_t)row0 * D;
@@ -61,6 +65,7 @@ __global__ __launch_bounds__(kTcThreads) void tc_fwd_kernel(const float* __restr
                                                             float* __restrict__ prodm, float* __restrict__ logqz,
                                                             float* __restrict__ lse, int Bt, int row_offset, int D,
                                                             TcConst c) {
+  const int kTcChunk = tc_chunk(D);
   extern __shared__ __attribute__((aligned(16))) float spart[];
   __shared__ float red[kTcThreads / 64];
   const int j = blockIdx.x, jg = row_offset + j;
@@ -157,6 +162,7 @@ __global__ __launch_bounds__(kTcThreads) void tc_bwd_rows_kernel(
     const float* __restrict__ logvar, const float* __restrict__ logqz, const float* __restrict__ lse,
     float* __restrict__ wq, float* __restrict__ dz, float* __restrict__ dlogvar, int Bt, int row_offset, int D,
     TcConst c) {
+  const int kTcChunk = tc_chunk(D);
   extern __shared__ __attribute__((aligned(16))) float spart[];
   const int j = blockIdx.x, jg = row_offset + j;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -233,6 +239,7 @@ __global__ __launch_bounds__(kTcThreads) void tc_bwd_cols_kernel(
     const float* __restrict__ g, const float* __restrict__ z, const float* __restrict__ mu_all,
     const float* __restrict__ logvar, const float* __restrict__ lse, const float* __restrict__ wq,
     float* __restrict__ dmu_all, int Bl, int Bt, int row_offset, int D, TcConst c) {
+  const int kTcChunk = tc_chunk(D);
   extern __shared__ __attribute__((aligned(16))) float cs[];   // z, logvar, lse rows [3][kTcChunk][D], then wq, g [2][kTcChunk]
   float* z_s = cs;
   float* lv_s = z_s + kTcChunk * D;
@@ -389,7 +396,7 @@ int itcv_tc_fwd(const float* z, const float* mu_all, const float* logvar, float*
   TcConst c;
   if (int e = make_const("itcv_tc_fwd", Bt, dataset_size, &c)) return e;
   const bool vrow = flags & ITCV_TC_VAR_FROM_ROW, eps = flags & ITCV_TC_EPS_DENSITY, mws = flags & ITCV_TC_WEIGHTED;
-  const size_t lds = ((size_t)(kTcThreads / 64) * Bt + (size_t)(vrow ? 1 : 2) * kTcChunk * D) * sizeof(float);
+  const size_t lds = ((size_t)(kTcThreads / 64) * Bt + (size_t)(vrow ? 1 : 2) * tc_chunk(D) * D) * sizeof(float);
   if (lds > 128 * 1024) return fail("%s: global batch %lld / latent size too large for the LDS row buffers", "itcv_tc_fwd", Bt);
   dim3 grid(Bl), block(kTcThreads);
   hipStream_t st = S(stream);
@@ -427,8 +434,8 @@ int itcv_tc_bwd(const float* g, const float* z, const float* mu_all, const float
   ITCV_REQUIRE(ws && ws_bytes >= (size_t)Bl * Bt * sizeof(float), "itcv_tc_bwd(workspace)");
   TcConst c;
   if (int e = make_const("itcv_tc_bwd", Bt, dataset_size, &c)) return e;
-  const size_t lds = ((size_t)(kTcThreads / 64) * Bt + (size_t)kTcChunk * D) * sizeof(float);
-  const size_t lds_c = ((size_t)3 * kTcChunk * D + 2 * kTcChunk) * sizeof(float);
+  const size_t lds = ((size_t)(kTcThreads / 64) * Bt + (size_t)tc_chunk(D) * D) * sizeof(float);
+  const size_t lds_c = ((size_t)3 * tc_chunk(D) * D + 2 * tc_chunk(D)) * sizeof(float);
   if (lds > 128 * 1024 || lds_c > 128 * 1024)
     return fail("%s: global batch %lld / latent size too large for the LDS row buffers", "itcv_tc_bwd", Bt);
   if (lds > 64 * 1024)
