@@ -2002,6 +2002,14 @@ static inline int pad32(int c) { return (c + 31) & ~31; }
 struct FwdPlanB {
   int bm, bn, mt, nt, cip, ktiles, splits, kps;
 };
+static int fwd_b_split_target() {   // blocks aimed at when K is split (ITCV_FWDB_BLOCKS overrides; diagnostic)
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("ITCV_FWDB_BLOCKS");
+    v = e ? atoi(e) : 256;   // one block per CU: half the slabs and prologues of a 512-block split (measured +2 % step)
+  }
+  return v;
+}
 static FwdPlanB plan_fwd_b(int B, int Ci, int H, int W, int Co, int KS) {
   FwdPlanB p;
   const long long N = (long long)B * H * W;
@@ -2014,7 +2022,7 @@ static FwdPlanB plan_fwd_b(int B, int Ci, int H, int W, int Co, int KS) {
   const int tiles = p.mt * p.nt;
   int splits = 1;
   if (tiles < 192 && p.ktiles >= 8) {
-    splits = cdiv(512, tiles);
+    splits = cdiv(fwd_b_split_target(), tiles);
     if (splits > p.ktiles / 4) splits = p.ktiles / 4;
     if (splits > 64) splits = 64;
     if (splits < 1) splits = 1;
