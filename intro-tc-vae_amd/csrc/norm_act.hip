@@ -661,7 +661,12 @@ static inline bool bn_fuse_finalize() {   // ITCV_BN_FUSE=0: always finalise in 
 
 static inline int bn_splits(int B, int C, int HW) {
   const size_t total = (size_t)B * HW;
-  int s = cdiv(2048, C);
+  static int target = -1;   // blocks aimed at by the sliced reductions (ITCV_BN_BLOCKS overrides; diagnostic)
+  if (target < 0) {
+    const char* e = getenv("ITCV_BN_BLOCKS");
+    target = e ? atoi(e) : 1024;
+  }
+  int s = cdiv(target, C);
   const size_t maxs = cdivz(total, 1024);
   if ((size_t)s > maxs) s = (int)maxs;
   if (s < 1) s = 1;
