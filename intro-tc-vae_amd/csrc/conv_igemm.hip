@@ -2153,8 +2153,13 @@ static FwdPlanP2 plan_fwd_p2(int B, int Ci, int H, int W, int Co, int KS, int ns
     return p;
   }
   int splits = 1;
+  static int target = -1;   // blocks aimed at when K is split (ITCV_P2_BLOCKS overrides; diagnostic)
+  if (target < 0) {
+    const char* e = getenv("ITCV_P2_BLOCKS");
+    target = e ? atoi(e) : 256;
+  }
   if (tiles < 192 && p.cpt >= 2) {
-    splits = 256 / tiles;
+    splits = target / tiles;
     if (splits > p.cpt) splits = p.cpt;
     if (splits < 1) splits = 1;
   }
@@ -2207,7 +2212,12 @@ static WgPlanP plan_wgrad_p(int B, int Ci, int H, int W, int Co) {
   p.tiles_m = cdiv(Co, p.bm), p.tiles_n = cdiv(Ci, p.bn);
   p.steps = (int)(((long long)B * H * W) / 64);
   const int T = p.tiles_m * p.tiles_n * 3;
-  int splits = 256 / T;                       // one 768-thread block per CU
+  static int target = -1;   // blocks aimed at (ITCV_WGP_BLOCKS overrides; diagnostic): one 768-thread block per CU
+  if (target < 0) {
+    const char* e = getenv("ITCV_WGP_BLOCKS");
+    target = e ? atoi(e) : 256;
+  }
+  int splits = target / T;
   if (splits > p.steps / 2) splits = p.steps / 2;
   if (splits < 1) splits = 1;
   p.sps = cdiv(p.steps, splits);
