@@ -108,6 +108,11 @@ int itcv_linear_wgrad(const float* dy, const float* x, float* dw, int B, int K, 
  * 32-row MFMA tile would be >90 % padding.  for_dgrad = 0: w is [Co][C][KS][KS]; for_dgrad = 1: w is the
  * forward layer's [C][Co][KS][KS] and its transposed, flipped filter is applied to x = dy. */
 int itcv_conv2d_small_cout_supported(int Co, int KS);
+/* The same layer on the bf16 matrix cores (bf16x3) from pre-split planes of a 64-channel input: MFMA rows are
+ * (output channel, filter column), every operand fragment is one plane chunk loaded straight from global memory. */
+int itcv_conv2d_small_cout_bf16p_supported(int C, int Co, int KS);
+int itcv_conv2d_small_cout_fwd_bf16p(const void* xplanes, const float* w, const float* bias, float* y, int B, int C,
+                                     int H, int W, int Co, int KS, int for_dgrad, void* stream);
 int itcv_conv2d_small_cout_fwd(const float* x, const float* w, const float* bias, float* y, int B, int C,
                                int H, int W, int Co, int KS, int for_dgrad, void* stream);
 /* ... and for layers with at most 4 REDUCTION channels (the 5x5 stem 3->64 forward, models.py:213, and

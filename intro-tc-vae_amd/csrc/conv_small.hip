@@ -118,6 +118,120 @@ __global__ __launch_bounds__(256) void conv_small_cin_kernel(const float* __rest
   }
 }
 
+// ---- <= 3 output channels from pre-split planes, on the bf16 matrix cores (bf16x3) -----------------------------
+// y[co][h][w] = sum_{ci,dh,dw} W[co][ci][dh][dw] x[ci][h+dh][w+dw] with 64 input channels given as planes.  The
+// MFMA rows are (co, dw) -- 15 of 16 used -- and its reduction index (dh, ci): Z[(co,dw)][h][w'] = sum_{dh,ci} W x[ci][h+dh][w']
+// needs no shift inside the GEMM, every B fragment is ONE 16-byte chunk of the planes (8 channels of a pixel) loaded
+// straight from global memory, and the weights (16 x 320 x 2 planes) live in registers.  A wave owns a strip of 16
+// input columns and walks down the rows: each input row (4 chunk loads per lane) feeds the five output rows it
+// touches (rolling accumulators), y[co][h][w] = sum_dw Z[(co,dw)][h][w+dw-2] is folded per finished row through a
+// 1-KB wave-private LDS tile; strips overlap by 4 columns (12 outputs per 16-column strip).
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+
+template <bool DGRAD>
+__global__ __launch_bounds__(256) void conv_small_cout_planes_kernel(const u32x4* __restrict__ xp,
+                                                                    const float* __restrict__ w,
+                                                                    const float* __restrict__ bias, float* __restrict__ y,
+                                                                    int B, int H, int W, int CO, int strips,
+                                                                    int row_blocks, int RB, size_t plane_stride,
+                                                                    int njobs) {
+  constexpr int KS = 5, KK = 25, C = 64, C8 = 8;
+  __shared__ float zs[4][16 * 17];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int job = blockIdx.x * 4 + wv;
+  if (job >= njobs) return;
+  const int s = job % strips, rbk = (job / strips) % row_blocks, b = job / (strips * row_blocks);
+  const int n = lane & 15, kg = lane >> 4;
+  const int h0 = rbk * RB, c0 = s * 12 - 2, wc = c0 + n;
+  const bool col_ok = (unsigned)wc < (unsigned)W;
+  const size_t HW = (size_t)H * W;
+
+  // A fragments: row m = (co, dw), k = 8 input channels (half*32 + kg*8 + j) of filter row dh; two bf16 planes
+  bf16x8 af[5][2][2];
+  {
+    const int m = n, co = m / 5, dw = m - co * 5;
+#pragma unroll
+    for (int dh = 0; dh < 5; ++dh)
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int c = hf * 32 + kg * 8 + j, tap = dh * KS + dw;
+          float t = 0.f;
+          if (co < CO) t = DGRAD ? w[((size_t)c * CO + co) * KK + (KK - 1 - tap)] : w[((size_t)co * C + c) * KK + tap];
+          v[j] = t;
+        }
+        u32x4 pl[2];
+        split8<2>(v, pl);
+        af[dh][hf][0] = __builtin_bit_cast(bf16x8, pl[0]);
+        af[dh][hf][1] = __builtin_bit_cast(bf16x8, pl[1]);
+      }
+  }
+  const u32x4 zero = {0u, 0u, 0u, 0u};
+  // B fragments of one input row: [half][plane], chunk (b, c8 = half*4 + kg, row, wc)
+  auto load_row = [&](int hr, u32x4 (&dst)[2][2]) {
+    const bool ok = col_ok && (unsigned)hr < (unsigned)H;
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+      for (int p = 0; p < 2; ++p)
+        dst[hf][p] = ok ? xp[(size_t)p * plane_stride + ((size_t)b * C8 + hf * 4 + kg) * HW + (size_t)hr * W + wc] : zero;
+  };
+  f32x4_t acc[5];
+#pragma unroll
+  for (int i = 0; i < 5; ++i) acc[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  const int nrows = min(RB, H - h0);       // output rows of this job
+  u32x4 cur[2][2], nxt[2][2];
+  load_row(h0 - 2, cur);
+  float* zt = zs[wv];
+  for (int i0 = 0; i0 < nrows + 4; i0 += 5) {
+#pragma unroll
+    for (int r = 0; r < 5; ++r) {
+      const int i = i0 + r;                // input row h0 - 2 + i
+      if (i >= nrows + 4) break;
+      load_row(h0 - 2 + i + 1, nxt);
+      // output row o = i - kh (kh = 0..4 = dh + 2) takes filter row kh; its accumulator slot is o mod 5
+#pragma unroll
+      for (int kh = 0; kh < 5; ++kh) {
+        const int slot = ((r - kh) % 5 + 5) % 5;
+        f32x4_t c = acc[slot];
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+          const bf16x8 b0 = __builtin_bit_cast(bf16x8, cur[hf][0]), b1 = __builtin_bit_cast(bf16x8, cur[hf][1]);
+          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[kh][hf][0], b1, c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[kh][hf][1], b0, c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[kh][hf][0], b0, c, 0, 0, 0);
+        }
+        acc[slot] = c;
+      }
+      // output row o = i - 4 is complete (slot (r - 4) mod 5 = (r + 1) mod 5)
+      const int o = i - 4, slot_done = (r + 1) % 5;
+      if (o >= 0) {
+        const f32x4_t z = acc[slot_done];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) zt[(4 * kg + q) * 17 + n] = z[q];   // Z[m = 4*kg + q][column n]
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (lane < 36) {
+          const int co = lane / 12, nn = lane - co * 12, wo = s * 12 + nn;
+          if (co < CO && wo < W) {
+            float v = bias ? bias[co] : 0.f;
+#pragma unroll
+            for (int dw = 0; dw < 5; ++dw) v += zt[(co * 5 + dw) * 17 + nn + dw];
+            y[(((size_t)b * CO + co) * H + (h0 + o)) * W + wo] = v;
+          }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      }
+      acc[slot_done] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+        for (int p = 0; p < 2; ++p) cur[hf][p] = nxt[hf][p];
+    }
+  }
+}
+
 }  // namespace itcv
 
 using namespace itcv;
@@ -164,6 +278,31 @@ int itcv_conv2d_small_cout_fwd(const float* x, const float* w, const float* bias
 #undef ITCV_SMALL_KS
 #undef ITCV_SMALL
   ITCV_CHECK_LAUNCH("itcv_conv2d_small_cout_fwd");
+  return 0;
+}
+
+// bf16x3 form of the <= 3-output 5x5 conv on pre-split planes of a 64-channel input ([2][B][8][H][W] chunks); same
+// result tensor as itcv_conv2d_small_cout_fwd up to the 2^-16-per-product rounding of the split.
+int itcv_conv2d_small_cout_bf16p_supported(int C, int Co, int KS) { return C == 64 && Co >= 1 && Co <= 3 && KS == 5; }
+
+int itcv_conv2d_small_cout_fwd_bf16p(const void* xplanes, const float* w, const float* bias, float* y, int B, int C,
+                                     int H, int W, int Co, int KS, int for_dgrad, void* stream) {
+  ITCV_REQUIRE(xplanes && w && y && B > 0 && H > 0 && W > 0, "itcv_conv2d_small_cout_fwd_bf16p");
+  if (!itcv_conv2d_small_cout_bf16p_supported(C, Co, KS))
+    return fail("%s: needs C == 64, Co <= 3, KS == 5", "itcv_conv2d_small_cout_fwd_bf16p");
+  const int strips = cdiv(W, 12), RB = H >= 16 ? 16 : H, row_blocks = cdiv(H, RB);
+  const int njobs = B * row_blocks * strips;
+  hipStream_t st = S(stream);
+  const size_t plane_stride = (size_t)B * 8 * H * W;
+  const u32x4* xp = static_cast<const u32x4*>(xplanes);
+  ProfScope prof(st, 4, KS, Co, 0, 2, 2.0 * B * H * W * (double)Co * C * KS * KS);
+  if (for_dgrad)
+    launch_timed(conv_small_cout_planes_kernel<true>, dim3(cdiv(njobs, 4)), dim3(256), 0, st, xp, w, bias, y, B, H, W, Co,
+                 strips, row_blocks, RB, plane_stride, njobs);
+  else
+    launch_timed(conv_small_cout_planes_kernel<false>, dim3(cdiv(njobs, 4)), dim3(256), 0, st, xp, w, bias, y, B, H, W, Co,
+                 strips, row_blocks, RB, plane_stride, njobs);
+  ITCV_CHECK_LAUNCH("itcv_conv2d_small_cout_fwd_bf16p");
   return 0;
 }
 

@@ -117,6 +117,7 @@ _CONV_MATH = [_os.environ.get("ITCV_CONV_MATH", "fp32")]
 assert _CONV_MATH[0] in _NS, "ITCV_CONV_MATH must be one of fp32 / bf16x3 / bf16x6"
 
 
+_SMALL_PLANES = [_os.environ.get("ITCV_SMALL_PLANES", "1") != "0"]   # matrix-core form of the 3-output 5x5 convs
 _POISON = [_os.environ.get("ITCV_POISON", "0") == "1"]   # diagnostic: fill planes-only tensors with NaN
 _PLANES = [_os.environ.get("ITCV_PLANES", "1") != "0"]   # split-bf16 convs take pre-split operands (LDS-DMA kernels)
 
@@ -218,6 +219,11 @@ def split_planes(x, ns):
 
 def conv_apply_planes(xp, weight, w4, for_dgrad, bias, B, Ci, H, W, Co, KS, up2, ns):
     """conv_apply with the input given as pre-split planes (LDS-DMA kernel, no gather)."""
+    if not up2 and ns == 2 and lib.itcv_conv2d_small_cout_bf16p_supported(Ci, Co, KS):
+        y = torch.empty((B, Co, H, W), dtype=F32, device=xp.device)
+        call("itcv_conv2d_small_cout_fwd_bf16p", ptr(xp), ptr(w4), ptr(bias), ptr(y), B, Ci, H, W, Co, KS, int(for_dgrad),
+             stream())
+        return y
     wp = packed_weight(weight, w4, for_dgrad, ns)
     y = torch.empty((B, Co, H, W), dtype=F32, device=xp.device)
     nws = lib.itcv_conv2d_fwd_bf16p_workspace(B, Ci, H, W, Co, KS, ns)
@@ -395,6 +401,8 @@ def _planes_ns(Ci, Co, KS, up2):
     ns = _NS[_CONV_MATH[0]]
     if not ns or not _PLANES[0]:
         return 0
+    if not up2 and ns == 2 and _SMALL_PLANES[0] and lib.itcv_conv2d_small_cout_bf16p_supported(Ci, Co, KS):
+        return 2    # the 5x5 predict conv / stem data-gradient on the matrix cores (bf16x3 only)
     if not up2 and (lib.itcv_conv2d_small_cout_supported(Co, KS) or lib.itcv_conv2d_small_cin_supported(Ci, KS)):
         return 0
     return ns if lib.itcv_conv2d_bf16s_supported(Ci, Co, KS) else 0

@@ -131,3 +131,20 @@ def test_batchnorm_emits_planes(HF, shape, pool):
     y2 = HF.BnActFn.apply(xd2, gd.detach(), bd.detach(), None, rm.clone(), rv.clone(), nbt.clone(), 1e-4, 0.1, 0.2, pool,
                           True, None, 2, 0, False, True)
     assert torch.equal(HF._tagged_planes(y2, 2), yp)
+
+
+@pytest.mark.parametrize("B,S,Co,dgrad", [(3, 16, 3, False), (2, 64, 3, True), (5, 32, 2, False), (2, 8, 1, True)])
+def test_small_cout_conv_on_planes(HF, B, S, Co, dgrad):
+    """The 5x5, <= 3-output conv (predict layer / stem data-gradient) on the bf16 matrix cores from planes of its
+    64-channel input: rows (co, dw), rolling row accumulators, dw fold -- against fp64 (bf16x3: 5e-5)."""
+    assert HF.lib.itcv_conv2d_small_cout_bf16p_supported(64, Co, 5)
+    g = torch.Generator().manual_seed(B * 100 + S + Co)
+    x = torch.randn(B, 64, S, S, generator=g)
+    w = torch.randn((64, Co, 5, 5) if dgrad else (Co, 64, 5, 5), generator=g) / 40.0
+    bias = None if dgrad else torch.randn(Co, generator=g)
+    wr = (w.flip(2, 3).transpose(0, 1) if dgrad else w).double()
+    ref = F.conv2d(x.double(), wr, None if bias is None else bias.double(), padding=2)
+    xp = HF.split_planes(x.to(dev()), 2)
+    got = HF.conv_apply_planes(xp, w.to(dev()), w.to(dev()), int(dgrad), None if bias is None else bias.to(dev()), B, 64,
+                               S, S, Co, 5, False, 2)
+    assert rel_err(got, ref) < 5e-5
