@@ -103,6 +103,13 @@ int itcv_linear_dgrad(const float* dy, const float* w, float* dx, int B, int K, 
                       void* stream);
 int itcv_linear_wgrad(const float* dy, const float* x, float* dw, int B, int K, int N, int accumulate, void* ws,
                       size_t ws_bytes, void* stream);
+/* 5x5 weight gradients with a <= 3-channel side (stem 3 -> 64: stem = 1, small = x, big_planes = planes of dy;
+ * predict 64 -> 3: stem = 0, small = dy, big_planes = planes of x), bf16x3 on the matrix cores: rows (small channel,
+ * filter column), pixel reduction through the transposing LDS read.  W in {32, 64}.  Deterministic slab reduce. */
+int itcv_conv2d_wgrad5_bf16p_supported(int Cs, int Cb, int H, int W);
+size_t itcv_conv2d_wgrad5_bf16p_workspace(int B, int H);
+int itcv_conv2d_wgrad5_bf16p(const float* small, const void* big_planes, float* dw, int B, int Cs, int H, int W,
+                             int stem, int accumulate, void* ws, size_t ws_bytes, void* stream);
 /* Direct (vector-ALU, exact fp32) convolution for layers with at most 4 output channels -- the 5x5
  * predict conv 64->3 (models.py:290) and the data-gradient of the 5x5 stem (models.py:213), where a
  * 32-row MFMA tile would be >90 % padding.  for_dgrad = 0: w is [Co][C][KS][KS]; for_dgrad = 1: w is the

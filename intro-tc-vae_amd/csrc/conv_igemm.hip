@@ -29,6 +29,7 @@
 namespace itcv {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr uint32_t kOobBase = 0x80000000u;  // + any soffset < 2^31 stays out of range
@@ -1768,6 +1769,120 @@ __global__ __launch_bounds__(768) void conv_wgrad_bf16p_kernel(WgradArgsP a) {
   }
 }
 
+// ---- 5x5 weight gradients with a 3-channel side (stem 3 -> 64, predict 64 -> 3), bf16x3, matrix cores ----------
+// OUT[(cs, dw)][dh][cb] = sum_{b,h,w} S[b][cs][h + sg*(dh-2)][w + sg*(dw-2)] * T[b][cb][h][w]
+//   S: the <= 3-channel tensor (fp32), T: the 64-channel tensor as planes; sg = +1 for the stem (S = x, T = dy) and
+//   -1 for the predict conv (S = dy, T = x, the sum re-indexed over x's pixel).
+// MFMA 16x16x32 rows are (cs, dw) -- 15 of 16 used; the reduction index is the pixel, so T's chunks (8 channels of a
+// pixel) are staged K-major in LDS and read back through ds_read_b64_tr_b16; S fragments are 8 consecutive pixels of
+// a (shifted) row, split in registers.  A wave owns a few image rows (T row staged once, used by the five S rows it
+// pairs with) and all 5 x 64 (dh, cb) accumulators; its partial result goes to a slab, folded by wgrad5_reduce.
+template <int SG>
+__global__ __launch_bounds__(256) void conv_wgrad5_planes_kernel(const float* __restrict__ sm, const u32x4* __restrict__ tp,
+                                                                float* __restrict__ slab, int B, int CS, int H, int W,
+                                                                int rows_per_job, int njobs, size_t plane_stride) {
+  constexpr int PXS = 68;                          // row stride of the staged T row: 4 (mod 16) chunks, see conv_wgrad_bf16p_kernel
+  constexpr int RSZ = 2 * 8 * PXS;                 // chunks per staged row ([plane][c8][px], up to 64 px)
+  __shared__ u32x4 rows[4][RSZ];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int job = blockIdx.x * 4 + wv;
+  if (job >= njobs) return;
+  const int jobs_per_img = (H + rows_per_job - 1) / rows_per_job;
+  const int b = job / jobs_per_img, h_lo = (job - b * jobs_per_img) * rows_per_job, h_hi = min(H, h_lo + rows_per_job);
+  const size_t HW = (size_t)H * W;
+  const int n = lane & 15, kg = lane >> 4;                 // A row m = n = (cs, dw); k group of 8 pixels
+  const int cs = n / 5, dw = n - cs * 5;
+  const bool row_used = cs < CS;
+  const int i16 = lane & 15, q = i16 >> 2, pp = i16 & 3;   // transposed-read lane roles
+  const uint32_t rbase = lds_addr(rows[wv]);
+  f32x4_t acc[5][4];
+#pragma unroll
+  for (int dh = 0; dh < 5; ++dh)
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) acc[dh][nt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  for (int h = h_lo; h < h_hi; ++h) {
+    // stage T row (b, h): 8 channel chunks x W pixels x 2 planes; lane = pixel (W <= 64)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // previous row's fragment reads are done (wave-private buffer)
+    if (lane < W) {
+#pragma unroll
+      for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+        for (int c8 = 0; c8 < 8; ++c8)
+          rows[wv][(pl * 8 + c8) * PXS + lane] = tp[(size_t)pl * plane_stride + ((size_t)b * 8 + c8) * HW + (size_t)h * W + lane];
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    for (int w0 = 0; w0 < W; w0 += 32) {
+      // B fragments: T^T, columns = 16 channels of N-tile nt, k = pixels w0 + 8*kg + {0..7}
+      bf16x8 bfr[4][2];
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) {
+          const uint32_t ad = rbase + (uint32_t)(((pl * 8 + 2 * nt + (pp >> 1)) * PXS + w0 + 8 * kg + q) * 16 + (pp & 1) * 8);
+          tr_read8(bfr[nt][pl], ad, ad + 64);
+        }
+#pragma unroll
+      for (int dh = 0; dh < 5; ++dh) {
+        // A fragment: S[b][cs][h + SG*(dh-2)][w0 + 8*kg + j + SG*(dw-2)], j = 0..7
+        const int hs = h + SG * (dh - 2), ws0 = w0 + 8 * kg + SG * (dw - 2);
+        float v[8];
+        const bool hok = row_used && (unsigned)hs < (unsigned)H;
+        const float* sp = sm + ((size_t)b * CS + (row_used ? cs : 0)) * HW + (size_t)(hok ? hs : 0) * W;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int ww = ws0 + j;
+          v[j] = (hok && (unsigned)ww < (unsigned)W) ? sp[ww] : 0.f;
+        }
+        u32x4 ap[2];
+        split8<2>(v, ap);
+        const bf16x8 a0 = __builtin_bit_cast(bf16x8, ap[0]), a1 = __builtin_bit_cast(bf16x8, ap[1]);
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+          f32x4_t c = acc[dh][nt];
+          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, bfr[nt][1], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, bfr[nt][0], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, bfr[nt][0], c, 0, 0, 0);
+          acc[dh][nt] = c;
+        }
+      }
+    }
+  }
+  // slab[job][m = (cs,dw) 0..15][dh][cb 0..63]; lane: column n -> cb = nt*16 + n, rows m = 4*kg + i
+  float* out = slab + (size_t)job * 16 * 5 * 64;
+#pragma unroll
+  for (int dh = 0; dh < 5; ++dh)
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) out[((4 * kg + i) * 5 + dh) * 64 + nt * 16 + n] = acc[dh][nt][i];
+}
+
+// dw (+)= sum_jobs slab: element e = (m = cs*5 + dw, dh, cb); stem: dW[cb][cs][dh][dw], predict: dW[cs][cb][dh][dw]
+// (16 threads per element walk the jobs, folded in a fixed order through LDS)
+__global__ __launch_bounds__(256) void wgrad5_reduce(const float* __restrict__ slab, float* __restrict__ dwt, int CS,
+                                                    int njobs, int stem, int accumulate) {
+  __shared__ float part[16][17];
+  const int e = threadIdx.x & 15, g = threadIdx.x >> 4;
+  const int total = CS * 5 * 5 * 64, i = blockIdx.x * 16 + e;   // i over (cs, dw, dh, cb)
+  float s = 0.f;
+  int dst = 0;
+  if (i < total) {
+    const int cb = i & 63, r = i >> 6, dh = r % 5, m = r / 5, cs = m / 5, dwi = m - cs * 5;
+    const float* p = slab + (size_t)((m * 5 + dh) * 64 + cb);
+    for (int k = g; k < njobs; k += 16) s += p[(size_t)k * (16 * 5 * 64)];
+    dst = stem ? ((cb * CS + cs) * 5 + dh) * 5 + dwi : ((cs * 64 + cb) * 5 + dh) * 5 + dwi;
+  }
+  part[g][e] = s;
+  __syncthreads();
+  if (g == 0 && i < total) {
+    float t = accumulate ? dwt[dst] : 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t += part[k][e];
+    dwt[dst] = t;
+  }
+}
+
 // dw[co][ci][tap] (+)= sum_s slab[s][tap][co][ci]: one thread per (tap, co, ci) -- slab reads coalesced along ci,
 // the slices summed in ascending order (fixed => bitwise reproducible), 8 loads in flight per thread so that the walk
 // over the slices is not one exposed memory round trip per slice.
@@ -2835,6 +2950,48 @@ int itcv_linear_wgrad(const float* dy, const float* x, float* dw, int B, int K, 
                       size_t ws_bytes, void* stream) {
   ITCV_REQUIRE(dy && x && dw && B > 0 && K > 0 && N > 0, "itcv_linear_wgrad");
   return run_gemm64("itcv_linear_wgrad", dy, x, nullptr, dw, N, K, B, 1, N, K, 1, accumulate, ws, ws_bytes, S(stream));
+}
+
+// ---- 5x5 weight gradient with a 3-channel side, from planes of the 64-channel side (bf16x3) -------------------
+// stem = 1: dw[64][Cs][5][5] for x[B][Cs][H][W] (fp32, `small`) and the planes of dy[B][64][H][W] (`big_planes`);
+// stem = 0: dw[Cs][64][5][5] for dy[B][Cs][H][W] (fp32, `small`) and the planes of x[B][64][H][W].
+int itcv_conv2d_wgrad5_bf16p_supported(int Cs, int Cb, int H, int W) {
+  return Cs >= 1 && Cs <= 3 && Cb == 64 && H > 0 && W >= 32 && W <= 64 && W % 32 == 0;
+}
+static inline int wgrad5_rows_per_job(int B, int H) {
+  int r = cdiv(B * H, 1024);      // ~1024 wave jobs (256 blocks of 4)
+  return r < 1 ? 1 : r;
+}
+size_t itcv_conv2d_wgrad5_bf16p_workspace(int B, int H) {
+  if (B <= 0 || H <= 0) return 0;
+  const int rpj = wgrad5_rows_per_job(B, H);
+  return (size_t)B * cdiv(H, rpj) * 16 * 5 * 64 * sizeof(float);
+}
+int itcv_conv2d_wgrad5_bf16p(const float* small, const void* big_planes, float* dw, int B, int Cs, int H, int W,
+                             int stem, int accumulate, void* ws, size_t ws_bytes, void* stream) {
+  ITCV_REQUIRE(small && big_planes && dw && B > 0, "itcv_conv2d_wgrad5_bf16p");
+  if (!itcv_conv2d_wgrad5_bf16p_supported(Cs, 64, H, W))
+    return fail("%s: needs Cs <= 3, 64 channels on the other side, W in {32, 64}", "itcv_conv2d_wgrad5_bf16p");
+  const int rpj = wgrad5_rows_per_job(B, H), njobs = B * cdiv(H, rpj);
+  const size_t need = (size_t)njobs * 16 * 5 * 64 * sizeof(float);
+  if (!ws || ws_bytes < need) return fail("%s: workspace too small (need %lld bytes)", "itcv_conv2d_wgrad5_bf16p", (long long)need);
+  hipStream_t st = S(stream);
+  const size_t plane_stride = (size_t)B * 8 * H * W;
+  {
+    ProfScope prof(st, 2, 5, 64, 0, 2, 2.0 * B * H * W * 64.0 * Cs * 25);
+    if (stem)
+      launch_timed(conv_wgrad5_planes_kernel<1>, dim3(cdiv(njobs, 4)), dim3(256), 0, st, small,
+                   static_cast<const u32x4*>(big_planes), static_cast<float*>(ws), B, Cs, H, W, rpj, njobs, plane_stride);
+    else
+      launch_timed(conv_wgrad5_planes_kernel<-1>, dim3(cdiv(njobs, 4)), dim3(256), 0, st, small,
+                   static_cast<const u32x4*>(big_planes), static_cast<float*>(ws), B, Cs, H, W, rpj, njobs, plane_stride);
+  }
+  ITCV_CHECK_LAUNCH("itcv_conv2d_wgrad5_bf16p");
+  const int total = Cs * 25 * 64;
+  hipLaunchKernelGGL(wgrad5_reduce, dim3(cdiv(total, 16)), dim3(256), 0, st, static_cast<const float*>(ws), dw, Cs, njobs,
+                     stem ? 1 : 0, accumulate);
+  ITCV_CHECK_LAUNCH("itcv_conv2d_wgrad5_bf16p(reduce)");
+  return 0;
 }
 
 // Which kernel instantiation / decomposition a call resolves to (for profiling buckets):

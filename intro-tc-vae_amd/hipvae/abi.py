@@ -51,6 +51,9 @@ SIGNATURES = {
     "itcv_linear_fwd": (i32, [p, p, p, p, i32, i32, i32, p, sz, p]),
     "itcv_linear_dgrad": (i32, [p, p, p, i32, i32, i32, p, sz, p]),
     "itcv_linear_wgrad": (i32, [p, p, p, i32, i32, i32, i32, p, sz, p]),
+    "itcv_conv2d_wgrad5_bf16p_supported": (i32, [i32] * 4),
+    "itcv_conv2d_wgrad5_bf16p_workspace": (sz, [i32, i32]),
+    "itcv_conv2d_wgrad5_bf16p": (i32, [p, p, p] + [i32] * 6 + [p, sz, p]),
     "itcv_conv2d_small_cout_supported": (i32, [i32, i32]),
     "itcv_conv2d_small_cout_bf16p_supported": (i32, [i32, i32, i32]),
     "itcv_conv2d_small_cout_fwd_bf16p": (i32, [p, p, p, p] + [i32] * 7 + [p]),

@@ -370,7 +370,9 @@ def conv_grad_planes_ns(conv, needs_input_grad=True):
         return 0
     ks = conv.kernel_size[0]
     ns = _planes_ns(conv.out_channels, conv.in_channels, ks, False) if needs_input_grad else 0
-    if not ns and _NS[_CONV_MATH[0]] == 2 and _PLANES[0] and ks == 3:
+    if not ns and _NS[_CONV_MATH[0]] == 2 and _PLANES[0] and (ks == 3 or (ks == 5 and _SMALL_PLANES[0]
+                                                                       and conv.in_channels <= 3
+                                                                       and conv.out_channels == 64)):
         ns = 2    # weight gradient on planes (shape support is re-checked where the planes are consumed)
     return ns
 
@@ -382,7 +384,9 @@ def conv_input_mode(conv, B, H, W, up2=False):
     if not ns:
         return 0, True
     ks = conv.kernel_size[0]
-    return ns, not (ns == 2 and _wgrad_planes_ok(B, conv.in_channels, H, W, conv.out_channels, ks))
+    wg_ok = (_wgrad_planes_ok(B, conv.in_channels, H, W, conv.out_channels, ks)
+             or _wgrad5_mode(conv.in_channels, H, W, conv.out_channels, ks, up2) == "predict")
+    return ns, not (ns == 2 and wg_ok)
 
 
 def conv_grad_mode(conv, B, H, W, needs_input_grad=True):
@@ -406,6 +410,28 @@ def _planes_ns(Ci, Co, KS, up2):
     if not up2 and (lib.itcv_conv2d_small_cout_supported(Co, KS) or lib.itcv_conv2d_small_cin_supported(Ci, KS)):
         return 0
     return ns if lib.itcv_conv2d_bf16s_supported(Ci, Co, KS) else 0
+
+
+def _wgrad5_mode(Ci, H, W, Co, KS, up2):
+    """'stem' / 'predict' when the 5x5 weight gradient with a 3-channel side runs on the matrix cores (bf16x3)."""
+    if up2 or KS != 5 or _NS[_CONV_MATH[0]] != 2 or not (_PLANES[0] and _SMALL_PLANES[0]):
+        return None
+    if Ci <= 3 and lib.itcv_conv2d_wgrad5_bf16p_supported(Ci, Co, H, W):
+        return "stem"
+    if Co <= 3 and lib.itcv_conv2d_wgrad5_bf16p_supported(Co, Ci, H, W):
+        return "predict"
+    return None
+
+
+def conv_wgrad5_planes(small, big_planes, B, Cs, H, W, stem, out=None, accumulate=False):
+    """5x5 weight gradient with a <= 3-channel side from the planes of the 64-channel side."""
+    dw = out if out is not None else torch.empty((64, Cs, 5, 5) if stem else (Cs, 64, 5, 5), dtype=F32, device=small.device)
+    nws = lib.itcv_conv2d_wgrad5_bf16p_workspace(B, H)
+    ws = _ws(nws, small.device)
+
+    call("itcv_conv2d_wgrad5_bf16p", ptr(small), ptr(big_planes), ptr(dw), B, Cs, H, W, int(stem), int(accumulate), ptr(ws),
+         nws, stream())
+    return dw
 
 
 def _wgrad_planes_ok(B, Ci, H, W, Co, KS):
@@ -434,7 +460,7 @@ class Conv2dFn(Function):
         else:
             y = conv_apply(_require_fp32(x, "Conv2dFn.forward"), weight, weight, 0, b, B, Ci, H, W, Co, KS, up2)
         wg_planes = _wgrad_planes_ok(B, Ci, H, W, Co, KS)
-        keep_xp = xp if (wg_planes and ns == 2) else None
+        keep_xp = xp if (ns == 2 and (wg_planes or _wgrad5_mode(Ci, H, W, Co, KS, up2) == "predict")) else None
         ctx.save_for_backward(None if keep_xp is not None else _require_fp32(x, "Conv2dFn.forward (saved input)"),
                               weight, bias, keep_xp)
         ctx.cfg = (B, Ci, H, W, Co, KS, up2, bias is not None, (Hs, Ws))
@@ -461,7 +487,24 @@ class Conv2dFn(Function):
                 lo = torch.empty((B, Ci, H // 2, W // 2), dtype=F32, device=dy.device)
                 call("itcv_upsample2_bwd", ptr(dx), ptr(lo), B * Ci, H // 2, W // 2, stream())
                 dx = lo
-        if ctx.needs_input_grad[1]:
+        wg5 = _wgrad5_mode(Ci, H, W, Co, KS, up2) if ctx.needs_input_grad[1] else None
+        if wg5 == "predict" and xp is None and x is None:
+            wg5 = None
+        if wg5 is not None:
+            tgt = _grad_target(weight)
+            if wg5 == "stem":
+                small, big = _require_fp32(x, "Conv2dFn.backward (5x5 weight gradient)"), (dyp if dyp is not None else planes_of(dy, 2))
+            else:
+                small, big = _require_fp32(dy, "Conv2dFn.backward (5x5 weight gradient)"), (xp if xp is not None else split_planes(x, 2))
+            cs = Ci if wg5 == "stem" else Co
+            if tgt is not None and _SIDE["enabled"]:
+                with _on_side_stream(dy.device, (small, big)):
+                    conv_wgrad5_planes(small, big, B, cs, H, W, wg5 == "stem", out=tgt, accumulate=True)
+            elif tgt is not None:
+                conv_wgrad5_planes(small, big, B, cs, H, W, wg5 == "stem", out=tgt, accumulate=True)
+            else:
+                dw = conv_wgrad5_planes(small, big, B, cs, H, W, wg5 == "stem")
+        elif ctx.needs_input_grad[1]:
             tgt = _grad_target(weight)
             if wg_planes and (ns_d in (0, 2)):
                 if xp is None:

@@ -148,3 +148,22 @@ def test_small_cout_conv_on_planes(HF, B, S, Co, dgrad):
     got = HF.conv_apply_planes(xp, w.to(dev()), w.to(dev()), int(dgrad), None if bias is None else bias.to(dev()), B, 64,
                                S, S, Co, 5, False, 2)
     assert rel_err(got, ref) < 5e-5
+
+
+@pytest.mark.parametrize("B,S,Cs,stem", [(3, 32, 3, True), (2, 64, 3, False), (5, 32, 2, False), (2, 64, 1, True)])
+def test_wgrad5_on_planes(HF, B, S, Cs, stem):
+    """5x5 weight gradient with a <= 3-channel side (stem / predict) on the bf16 matrix cores: rows (channel, dw),
+    pixel reduction through the transposing LDS read -- against fp64 (bf16x3: 5e-5), accumulate form, bitwise repeatable."""
+    assert HF.lib.itcv_conv2d_wgrad5_bf16p_supported(Cs, 64, S, S)
+    g = torch.Generator().manual_seed(B * 10 + S + Cs)
+    Ci, Co = (Cs, 64) if stem else (64, Cs)
+    x = torch.randn(B, Ci, S, S, generator=g)
+    dy = torch.randn(B, Co, S, S, generator=g)
+    ref = torch.nn.grad.conv2d_weight(x.double(), (Co, Ci, 5, 5), dy.double(), padding=2)
+    small, big = (x, dy) if stem else (dy, x)
+    bp = HF.split_planes(big.to(dev()), 2)
+    dw = HF.conv_wgrad5_planes(small.to(dev()), bp, B, Cs, S, S, stem)
+    assert rel_err(dw, ref) < 5e-5
+    acc = HF.conv_wgrad5_planes(small.to(dev()), bp, B, Cs, S, S, stem, out=dw.clone(), accumulate=True)
+    assert rel_err(acc, 2 * ref) < 5e-5
+    assert torch.equal(dw, HF.conv_wgrad5_planes(small.to(dev()), bp, B, Cs, S, S, stem))
