@@ -147,7 +147,33 @@ def _load():
     return lib
 
 
-lib = _load()
+class _Lib:
+    """The loaded library with its pure query entry points (``*_supported``, ``*_workspace``, ``*_bytes``, ``*_elems``,
+    ``*_variant``: integers in, integer out, no device work) memoised: an eager step asks several thousand such
+    questions, and a dict hit is ~10x cheaper than a ctypes call."""
+
+    _PURE = ("_supported", "_workspace", "_bytes", "_elems", "_variant")
+
+    def __init__(self, cdll):
+        object.__setattr__(self, "_cdll", cdll)
+
+    def __getattr__(self, name):
+        fn = getattr(self._cdll, name)
+        if name.endswith(self._PURE):
+            memo = {}
+
+            def cached(*args, _fn=fn, _memo=memo):
+                r = _memo.get(args)
+                if r is None:
+                    r = _memo[args] = _fn(*args)
+                return r
+
+            fn = cached
+        object.__setattr__(self, name, fn)
+        return fn
+
+
+lib = _Lib(_load())
 
 
 def last_error():
