@@ -186,7 +186,8 @@ def check(rc, exc=RuntimeError):
 
 
 def stream():
-    return torch.cuda.current_stream().cuda_stream
+    """Raw handle of torch's current HIP stream (torch.cuda.current_stream() builds a Stream object: ~9 us a call)."""
+    return torch._C._cuda_getCurrentRawStream(torch.cuda.current_device())
 
 
 def ptr(t):
