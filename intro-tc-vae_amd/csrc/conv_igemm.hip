@@ -1606,6 +1606,7 @@ struct WgradArgsP {
   int steps, steps_per_split, splits;
   int h_shift;
   size_t xplane, dyplane;   // chunks per plane
+  int debug;                // diagnostic only (ITCV_ABLATE & 64): block 0 reports main-loop shader cycles / steps in slab[0..1]
 };
 
 __device__ __forceinline__ void tr_read8(bf16x8& dst, uint32_t addr0, uint32_t addr1) {
@@ -1617,8 +1618,8 @@ __device__ __forceinline__ void tr_read8(bf16x8& dst, uint32_t addr0, uint32_t a
   dst = __builtin_bit_cast(bf16x8, v);
 }
 
-template <int LOG2W, bool UP2, int BM, int BN>
-__global__ __launch_bounds__(768) void conv_wgrad_bf16p_kernel(WgradArgsP a) {
+template <int LOG2W, bool UP2, int BM, int BN, int NST, int NLW>
+__global__ __launch_bounds__(512 + 64 * NLW) void conv_wgrad_bf16p_kernel(WgradArgsP a) {
   constexpr int W = 1 << LOG2W, NR = 64 >> LOG2W, WP = W + 2, NP = NR * WP;   // band: NR rows x (W+2) columns
   constexpr int PXA = 68, PXB = ((NP + 11) / 16) * 16 + 4;                     // row strides = 4 (mod 16) chunks: conflict-free tr reads
   static_assert(PXB >= NP && PXB % 16 == 4, "band stride");
@@ -1660,8 +1661,8 @@ __global__ __launch_bounds__(768) void conv_wgrad_bf16p_kernel(WgradArgsP a) {
       {
         const int g = st * 64 + lane, b = g / HW, pix = g - b * HW;
 #pragma unroll
-        for (int j = 0; j < 2 * ACH / 4; ++j) {
-          const int qq = j * 4 + lw, pl = qq / ACH, c8 = qq % ACH;
+        for (int j = 0; j < 2 * ACH / NLW; ++j) {
+          const int qq = j * NLW + lw, pl = qq / ACH, c8 = qq % ACH;
           const int gc8 = (co0 >> 3) + c8;
           const u32x4* src = a.dyp + ((size_t)pl * a.dyplane + ((size_t)b * Co8 + gc8) * HW + pix);
           lds_dma16(gc8 < Co8 ? src : zero, sbase + (uint32_t)((pl * ACH + c8) * PXA) * 16u);
@@ -1673,8 +1674,8 @@ __global__ __launch_bounds__(768) void conv_wgrad_bf16p_kernel(WgradArgsP a) {
         const bool valid = w_ok && (unsigned)hh < (unsigned)H;
         const int spix = UP2 ? (hh >> 1) * Ws + (w >> 1) : hh * W + w;
 #pragma unroll
-        for (int j = 0; j < 4 * BCH / 4; ++j) {
-          const int qq = (j * 4 + lw) >> 1, pl = qq / BCH, c8 = qq % BCH;
+        for (int j = 0; j < 4 * BCH / NLW; ++j) {
+          const int qq = (j * NLW + lw) >> 1, pl = qq / BCH, c8 = qq % BCH;
           const int gc8 = (ci0 >> 3) + c8;
           const u32x4* src = a.xp + ((size_t)pl * a.xplane + ((size_t)b * Ci8 + gc8) * HWs + spix);
           if (hp_active)
@@ -1683,14 +1684,28 @@ __global__ __launch_bounds__(768) void conv_wgrad_bf16p_kernel(WgradArgsP a) {
         }
       }
     };
+    // NST-deep ring: NST-1 steps in flight ahead of the one being multiplied (measured with two stages: a step took
+    // ~4300 cycles against 2304 of MFMA work -- one step of lookahead does not cover the ~50 KB / 30 B/clk ingest
+    // plus its latency).  Every piece below is issued by every loader wave, so the counted waits are exact.
+    constexpr int PST = 2 * ACH / NLW + 4 * BCH / NLW;   // pieces per loader wave per step
     issue(s0, 0);
-    wait_vmcnt<0>();
-    __builtin_amdgcn_s_barrier();
-    int stage = 1;
-    for (int st = s0; st < s1; ++st) {
-      if (st + 1 < s1) issue(st + 1, stage);
-      stage ^= 1;
+    if (NST == 3 && s0 + 1 < s1) {
+      issue(s0 + 1, 1);
+      wait_vmcnt<PST>();
+    } else {
       wait_vmcnt<0>();
+    }
+    __builtin_amdgcn_s_barrier();
+    int stage = NST - 1;
+    for (int st = s0; st < s1; ++st) {
+      if (st + NST - 1 < s1) {
+        issue(st + NST - 1, stage);                  // into the slot step st-1 has just left
+        if (NST == 3) wait_vmcnt<PST>();             // step st+1 has landed, st+2 may be in flight
+        else wait_vmcnt<0>();
+      } else {
+        wait_vmcnt<0>();
+      }
+      if (++stage == NST) stage = 0;
       __builtin_amdgcn_s_barrier();
     }
     return;
@@ -1720,6 +1735,7 @@ __global__ __launch_bounds__(768) void conv_wgrad_bf16p_kernel(WgradArgsP a) {
     }
     __builtin_amdgcn_s_barrier();
     int stage = 0;
+    const long long dbg_c0 = a.debug ? clock64() : 0;
     for (int st = s0; st < s1; ++st) {
       const uint32_t sb = smem_base + (uint32_t)(stage * SSZ) * 16u;
 #pragma unroll
@@ -1747,9 +1763,13 @@ __global__ __launch_bounds__(768) void conv_wgrad_bf16p_kernel(WgradArgsP a) {
             acc[tp][j] = c;
           }
       }
-      stage ^= 1;
+      if (++stage == NST) stage = 0;
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
+    }
+    if (a.debug && t == 0 && blockIdx.x == 0) {
+      a.slab[0] = (float)(clock64() - dbg_c0), a.slab[1] = (float)(s1 - s0);
+      return;
     }
   }
   // slab[split][tap][co][ci]
@@ -2343,15 +2363,18 @@ static WgPlanP plan_wgrad_p(int B, int Ci, int H, int W, int Co) {
 template <int LOG2W, bool UP2, int BM, int BN>
 static void launch_wgrad_p_cfg(const WgradArgsP& a, int blocks, hipStream_t st) {
   constexpr int W = 1 << LOG2W, NP = (64 >> LOG2W) * (W + 2), PXB = ((NP + 11) / 16) * 16 + 4;
-  constexpr size_t lds = (size_t)2 * (2 * (BM / 8) * 68 + 2 * (BN / 8) * PXB) * 16;
+  constexpr size_t stage_bytes = (size_t)(2 * (BM / 8) * 68 + 2 * (BN / 8) * PXB) * 16;
+  constexpr int NST = 3 * stage_bytes <= 160 * 1024 ? 3 : 2;     // three stages where LDS allows (W = 32 / 64 bands)
+  constexpr size_t lds = NST * stage_bytes;
   if constexpr (lds <= 160 * 1024) {
-    auto kern = conv_wgrad_bf16p_kernel<LOG2W, UP2, BM, BN>;
+    constexpr int NLW = 4;   // loader waves (eight were measured no faster, and spill in the 128 x 128 form)
+    auto kern = conv_wgrad_bf16p_kernel<LOG2W, UP2, BM, BN, NST, NLW>;
     static bool attr_set = false;
     if (!attr_set) {
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       attr_set = true;
     }
-    launch_timed(kern, dim3(blocks), dim3(768), lds, st, a);
+    launch_timed(kern, dim3(blocks), dim3(512 + 64 * NLW), lds, st, a);
   }
 }
 template <int LOG2W>
@@ -2846,6 +2869,14 @@ int itcv_conv2d_wgrad_bf16p(const void* xplanes, const void* dyplanes, float* dw
   a.h_shift = log2_exact(H);
   a.xplane = (size_t)B * (Ci / 8) * (up2 ? (H / 2) * (W / 2) : H * W);
   a.dyplane = (size_t)B * (Co / 8) * H * W;
+  {
+    static int dbg = -1;
+    if (dbg < 0) {
+      const char* e = getenv("ITCV_ABLATE");
+      dbg = (e && (atoi(e) & 64)) ? 1 : 0;
+    }
+    a.debug = dbg;
+  }
   hipStream_t st = S(stream);
   const int blocks = p.tiles_m * p.tiles_n * 3 * p.splits;
   {
