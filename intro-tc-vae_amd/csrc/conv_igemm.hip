@@ -1149,31 +1149,46 @@ __global__ __launch_bounds__(768) void conv_fwd_bf16p2_kernel(ConvArgsP2 a) {
         if (tap >= 9) continue;
         const int tapoff = ((tap / 3 - 1) * WP + (tap % 3 - 1)) * 16;
         const uint32_t ab = smem_base + (uint32_t)((slot * G + u) * ASZ) * 16u + aoff;
+        // all fragments of the K-tile (both 16-wide k-steps) are requested up front and the scheduler is told to
+        // interleave: the first k-step's reads, then one read of the second k-step behind each of the first MFMAs --
+        // left alone it parks most reads directly in front of their use (`s_waitcnt lgkmcnt(0)` before the MFMA)
+        bf16x8 af[2][NS][TM], bfr[2][NS][TN];
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
           const int kc = ks * 2 + half;
-          bf16x8 af[NS][TM], bfr[NS][TN];
 #pragma unroll
           for (int pp = 0; pp < NS; ++pp) {
 #pragma unroll
             for (int i = 0; i < TM; ++i)
-              af[pp][i] = __builtin_bit_cast(
+              af[ks][pp][i] = __builtin_bit_cast(
                   bf16x8, *(const __attribute__((address_space(3))) u32x4*)(size_t)(ab + (uint32_t)(((pp * KC + kc) * BM + i * 32) * 16)));
 #pragma unroll
             for (int j = 0; j < TN; ++j)
-              bfr[pp][j] = __builtin_bit_cast(
+              bfr[ks][pp][j] = __builtin_bit_cast(
                   bf16x8, *(const __attribute__((address_space(3))) u32x4*)(size_t)(bb + (uint32_t)((pp * KC + kc) * PXB) * 16u + hoff[j] + tapoff));
           }
+        }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
           for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
               f32x16 c = acc[i][j];
-              c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bfr[1][j], c, 0, 0, 0);
-              c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][i], bfr[0][j], c, 0, 0, 0);
-              c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bfr[0][j], c, 0, 0, 0);
+              c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks][0][i], bfr[ks][1][j], c, 0, 0, 0);
+              c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks][1][i], bfr[ks][0][j], c, 0, 0, 0);
+              c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks][0][i], bfr[ks][0][j], c, 0, 0, 0);
               acc[i][j] = c;
             }
+        {
+          constexpr int RD = NS * (TM + TN), MF = TM * TN * 3;   // LDS reads / MFMAs per k-step
+          __builtin_amdgcn_sched_group_barrier(0x100, RD, 0);
+#pragma unroll
+          for (int r = 0; r < RD; ++r) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+          }
+          __builtin_amdgcn_sched_group_barrier(0x008, 2 * MF - RD, 0);
         }
       }
       if (++slot == 3) slot = 0;
