@@ -1753,6 +1753,51 @@ __global__ __launch_bounds__(512 + 64 * NLW) void conv_wgrad_bf16p_kernel(WgradA
     const long long dbg_c0 = a.debug ? clock64() : 0;
     for (int st = s0; st < s1; ++st) {
       const uint32_t sb = smem_base + (uint32_t)(stage * SSZ) * 16u;
+      if constexpr (TNw == 1) {
+        // register double buffer over the four k-steps: the 16 transposed reads of k-step kk+1 are interleaved (two
+        // behind each MFMA, by scheduler group hints) with the 9 MFMAs of k-step kk instead of sitting in front of
+        // their own use
+        bf16x8 af[2][2], bfr[2][3][2];
+        auto fetch = [&](int kk, int bufi) {
+#pragma unroll
+          for (int pl = 0; pl < 2; ++pl) {
+            const uint32_t ad = sb + aoff + (uint32_t)(pl * ACH * PXA * 16 + kk * 256);
+            tr_read8(af[bufi][pl], ad, ad + 64);
+          }
+#pragma unroll
+          for (int tp = 0; tp < 3; ++tp)
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) {
+              const uint32_t bd = sb + boff + (uint32_t)(pl * BCH * PXB * 16 + (tp - 1) * 16);
+              tr_read8(bfr[bufi][tp][pl], bd + hidx16[kk * 2], bd + hidx16[kk * 2 + 1]);
+            }
+        };
+        fetch(0, 0);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+          const int cur = kk & 1;
+          if (kk + 1 < 4) fetch(kk + 1, cur ^ 1);
+#pragma unroll
+          for (int tp = 0; tp < 3; ++tp) {
+            f32x16 c = acc[tp][0];
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[cur][0], bfr[cur][tp][1], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[cur][1], bfr[cur][tp][0], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[cur][0], bfr[cur][tp][0], c, 0, 0, 0);
+            acc[tp][0] = c;
+          }
+          if (kk == 0) __builtin_amdgcn_sched_group_barrier(0x100, 16, 0);   // the first k-step's own reads
+          if (kk + 1 < 4) {
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+              __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+              __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          } else {
+            __builtin_amdgcn_sched_group_barrier(0x008, 9, 0);
+          }
+        }
+      } else {
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk) {
         bf16x8 af[2];
@@ -1777,6 +1822,7 @@ __global__ __launch_bounds__(512 + 64 * NLW) void conv_wgrad_bf16p_kernel(WgradA
             c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bfr[0], c, 0, 0, 0);
             acc[tp][j] = c;
           }
+      }
       }
       if (++stage == NST) stage = 0;
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
