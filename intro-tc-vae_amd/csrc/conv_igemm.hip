@@ -912,35 +912,49 @@ __global__ __launch_bounds__(512) void conv_fwd_bf16p_kernel(ConvArgsP a) {
   for (int it = 0; it < nk; ++it) {
     const u32x4* Ab = smem + slot * SSZ;
     const u32x4* Bb = Ab + ASZ;
+    if (!(a.ablate & 8)) {
+      // both k-steps' fragments requested up front, reads interleaved behind the MFMAs (see conv_fwd_bf16p2_kernel)
+      bf16x8 af[2][NS][TM], bfr[2][NS][TN];
 #pragma unroll
-    for (int ks = 0; ks < BK / 16; ++ks) {
-      if (a.ablate & 8) break;
-      const int kc = ks * 2 + half;
-      bf16x8 af[NS][TM], bfr[NS][TN];
+      for (int ks = 0; ks < BK / 16; ++ks) {
+        const int kc = ks * 2 + half;
 #pragma unroll
-      for (int pp = 0; pp < NS; ++pp) {
+        for (int pp = 0; pp < NS; ++pp) {
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
-          af[pp][i] = __builtin_bit_cast(bf16x8, Ab[(pp * KC + kc) * BM + wm * WTM + i * 32 + l31]);
+          for (int i = 0; i < TM; ++i)
+            af[ks][pp][i] = __builtin_bit_cast(bf16x8, Ab[(pp * KC + kc) * BM + wm * WTM + i * 32 + l31]);
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
-          bfr[pp][j] = __builtin_bit_cast(bf16x8, Bb[(pp * KC + kc) * BN + wn * WTN + j * 32 + l31]);
+          for (int j = 0; j < TN; ++j)
+            bfr[ks][pp][j] = __builtin_bit_cast(bf16x8, Bb[(pp * KC + kc) * BN + wn * WTN + j * 32 + l31]);
+        }
       }
 #pragma unroll
-      for (int i = 0; i < TM; ++i)
+      for (int ks = 0; ks < BK / 16; ++ks)
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-          f32x16 c = acc[i][j];
-          if constexpr (NS == 3) {
-            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][i], bfr[1][j], c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bfr[2][j], c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2][i], bfr[0][j], c, 0, 0, 0);
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) {
+            f32x16 c = acc[i][j];
+            if constexpr (NS == 3) {
+              c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks][1][i], bfr[ks][1][j], c, 0, 0, 0);
+              c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks][0][i], bfr[ks][2][j], c, 0, 0, 0);
+              c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks][2][i], bfr[ks][0][j], c, 0, 0, 0);
+            }
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks][0][i], bfr[ks][1][j], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks][1][i], bfr[ks][0][j], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks][0][i], bfr[ks][0][j], c, 0, 0, 0);
+            acc[i][j] = c;
           }
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bfr[1][j], c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][i], bfr[0][j], c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bfr[0][j], c, 0, 0, 0);
-          acc[i][j] = c;
+      if constexpr (NS == 2) {
+        constexpr int RD = NS * (TM + TN), MF = TM * TN * 3;
+        __builtin_amdgcn_sched_group_barrier(0x100, RD, 0);
+#pragma unroll
+        for (int r = 0; r < RD; ++r) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
         }
+        __builtin_amdgcn_sched_group_barrier(0x008, 2 * MF - RD, 0);
+      }
     }
     if (++slot == NSTAGE) slot = 0;
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this tile's fragments are in registers
