@@ -102,6 +102,20 @@ def average_(flat):
         dist.all_reduce(flat, op=dist.ReduceOp.AVG, group=c.group)
 
 
+def average_async(flat):
+    """average_ started asynchronously on the collective's own stream (RCCL): returns ``finish()``, which orders the
+    current stream after the collective.  Work that does not touch ``flat`` may be issued in between (the intro
+    solvers run the next phase's decoder-only forwards there).  gloo and single-process runs finish immediately."""
+    c = get()
+    if c is None:
+        return lambda: None
+    if dist.get_backend(c.group) == "gloo":
+        average_(flat)
+        return lambda: None
+    work = dist.all_reduce(flat, op=dist.ReduceOp.AVG, group=c.group, async_op=True)
+    return work.wait
+
+
 def mean_scalars_(vec):
     """Average a small vector of per-rank loss scalars so every rank reports the global value."""
     c = get()

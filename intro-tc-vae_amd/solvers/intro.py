@@ -50,14 +50,18 @@ class IntroSolver(VAESolver):
         expelbo_rec = self._exp_elbo(self.compute_rec_loss(rec, rec_rec, reduction="none"), kl_rec)
         expelbo_fake = self._exp_elbo(self.compute_rec_loss(fake, rec_fake, reduction="none"), kl_fake)
         loss_e = scale * (loss_rec + loss_e_real_kl) + 0.25 * (expelbo_rec + expelbo_fake)
-        self._backward(loss_e, ("encoder",))
-        norm_e = self._clip()
-        self._step("encoder")
+        finish_average = self._backward(loss_e, ("encoder",), defer_average=True)
 
         # ================= update D (encoder frozen) ======================== intro.py:118-160
+        # The two decoder-only forwards of this phase depend neither on the encoder's gradients nor on its update:
+        # they are issued while the encoder-gradient all-reduce is in flight (data-parallel runs), then the encoder
+        # update completes.  Single-process: same kernels, same results, commuting order.
         self._set_trainable(encoder=False, decoder=True)
         fake = model.sample(noise_batch)
         rec = model.decoder(z.detach())
+        finish_average()
+        norm_e = self._clip()
+        self._step("encoder")
         loss_rec = self.compute_rec_loss(real, rec, reduction="mean", write=True)
         rec_mu, rec_logvar = model.encode(rec)
         z_rec = reparameterize(rec_mu, rec_logvar)

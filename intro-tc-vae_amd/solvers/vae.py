@@ -92,16 +92,22 @@ class VAESolver:
         for p in self._params("decoder"):
             p.requires_grad = decoder
 
-    def _backward(self, loss, parts):
-        """optimizer.zero_grad() of ``parts`` + loss.backward() + gradient averaging over ranks."""
+    def _backward(self, loss, parts, defer_average=False):
+        """optimizer.zero_grad() of ``parts`` + loss.backward() + gradient averaging over ranks.  With
+        ``defer_average`` the all-reduces are only started; the returned callable finishes them (data-parallel runs
+        overlap them with work that does not depend on the averaged gradients)."""
         groups = [self._group(p) for p in parts]
         for g in groups:
             g.zero_grad()
         with direct_grad_accumulation():     # wgrad / BN / bias kernels add straight into the flat buffers
             loss.backward()
         side_join()                          # weight gradients were issued on the side stream
+        if defer_average:
+            pending = [ddp.average_async(g.flat_g) for g in groups]
+            return lambda: [f() for f in pending]
         for g in groups:
             ddp.average_(g.flat_g)
+        return None
 
     def _clip(self):
         """clip_grad_norm_ over ALL parameters with a gradient, stale frozen-half gradients included
