@@ -18,22 +18,24 @@ _ctx = None
 
 
 class Context:
-    def __init__(self, group=None, sync_bn=True):
+    def __init__(self, group=None, sync_bn=True, force=False):
         self.group = group
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
         self.sync_bn = sync_bn
+        self.active = self.world > 1 or force
 
 
-def init(group=None, sync_bn=True):
-    """Activate data-parallel behaviour for every solver / BatchNorm in this process."""
+def init(group=None, sync_bn=True, force=False):
+    """Activate data-parallel behaviour for every solver / BatchNorm in this process.  ``force`` keeps the
+    collectives on for a group of ONE rank (a one-GPU rig exercising the RCCL branches; results are unchanged)."""
     global _ctx
     if not dist.is_initialized():
         raise RuntimeError("torch.distributed is not initialised")
-    _ctx = Context(group if group is not None else dist.group.WORLD, sync_bn)
+    _ctx = Context(group if group is not None else dist.group.WORLD, sync_bn, force)
     try:
         import models
-        models.HipBatchNorm2d.sync_group = _ctx.group if (sync_bn and _ctx.world > 1) else None
+        models.HipBatchNorm2d.sync_group = _ctx.group if (sync_bn and _ctx.active) else None
     except ImportError:  # models not importable in pure-host tests of this module
         pass
     return _ctx
@@ -50,7 +52,7 @@ def shutdown():
 
 
 def get():
-    return _ctx if (_ctx is not None and _ctx.world > 1) else None
+    return _ctx if (_ctx is not None and _ctx.active) else None
 
 
 class _AllGatherRows(Function):

@@ -26,12 +26,16 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _setup(rank, world, port):
+def _setup(rank, world, port, backend="gloo"):
     for p in (os.path.join(ROOT, "intro-tc-vae_amd"), ROOT):
         if p not in sys.path:
             sys.path.insert(0, p)
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    if backend == "nccl":
+        torch.cuda.set_device(0)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda:0"))
+    else:
+        dist.init_process_group(backend, rank=rank, world_size=world)
 
 
 def _cpu_worker(rank, world, port, out):
@@ -87,13 +91,17 @@ def test_ddp_collective_algebra_cpu():
         assert dict(out) == {0: True, 1: True}
 
 
-def _gpu_worker(rank, world, port, out):
-    _setup(rank, world, port)
+def _gpu_worker(rank, world, port, out, backend="gloo"):
+    _setup(rank, world, port, backend)
     import models
     import ops
     from hipvae import ddp
     from solvers.intro_tc import IntroTCSovler
-    ddp.init(sync_bn=True)
+    # nccl on the one GPU of the box: a group of ONE rank with the data-parallel paths forced on, so that every
+    # collective of the step (async AVG all-reduce + wait, all_gather_into_tensor / reduce_scatter_tensor, Sync-BN
+    # moments) goes through RCCL on the device
+    ctx = ddp.init(sync_bn=True, force=(backend == "nccl"))
+    assert ddp.get() is ctx
     dev = torch.device("cuda:0")
     g = np.load(os.path.join(GOLDEN, "steps_conv.npz"))
     hp = g["hp"]
@@ -107,7 +115,7 @@ def _gpu_worker(rank, world, port, out):
             return int(hp[6])
 
     B = 8
-    Bl = B // world
+    Bl = B // dist.get_world_size()
     sl = slice(rank * Bl, (rank + 1) * Bl)
     solver = IntroTCSovler(DS(), model, Bl, torch.optim.Adam(model.encoder.parameters(), lr=hp[5]),
                            torch.optim.Adam(model.decoder.parameters(), lr=hp[5]), "mse", hp[0], hp[1], hp[2], hp[3],
@@ -144,3 +152,18 @@ def test_ddp_step_matches_single_process_golden():
             np.testing.assert_allclose(res[r]["res"][s], g[f"intro_tc:s{s}:dict"], rtol=1e-4 if s == 0 else 1e-3)
         assert res[r]["max"] <= 2.05 * 2e-4 * 2 and res[r]["frac"] < 5e-3 and res[r]["run"] < 1e-3
     assert res[0]["res"] == res[1]["res"]          # every rank reports the global scalars
+
+
+@pytest.mark.gpu
+def test_ddp_step_through_rccl_single_rank():
+    """backend "nccl" (= RCCL) on the one device of the test box: the step's collectives run on the GPU through the
+    production (non-gloo) branches of hipvae.ddp and must leave the golden single-process step unchanged."""
+    port = _free_port()
+    g = np.load(os.path.join(GOLDEN, "steps_conv.npz"))
+    with mp.Manager() as m:
+        out = m.dict()
+        mp.spawn(_gpu_worker, args=(1, port, out, "nccl"), nprocs=1, join=True)
+        res = dict(out)
+    for s in range(2):
+        np.testing.assert_allclose(res[0]["res"][s], g[f"intro_tc:s{s}:dict"], rtol=1e-4 if s == 0 else 1e-3)
+    assert res[0]["max"] <= 2.05 * 2e-4 * 2 and res[0]["frac"] < 5e-3 and res[0]["run"] < 1e-3
