@@ -127,6 +127,13 @@ def main():
         local_rank %= max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    # ITCV_BENCH_FORCE_DDP=1 (one-GPU rigs): a group of ONE rank with the data-parallel code paths on, so the step's
+    # collectives run through RCCL on the device -- the launch-side cost of the N>1 path without the wire time
+    force_ddp = world == 1 and os.environ.get("ITCV_BENCH_FORCE_DDP", "0") == "1"
+    if force_ddp:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29541")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
@@ -141,8 +148,8 @@ def main():
     from hipvae import functional as HF
     from solvers.intro_tc import IntroTCSovler
 
-    if world > 1:
-        ddp.init(sync_bn=args.sync_bn)
+    if world > 1 or force_ddp:
+        ddp.init(sync_bn=args.sync_bn, force=force_ddp)
     torch.manual_seed(0)
     with contextlib.redirect_stdout(io.StringIO()):
         model = models.SoftIntroVAE(arch="conv", **CFG)
@@ -160,7 +167,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    use_graph = world == 1 and not args.no_graph
+    # N>1: eager unless ITCV_DDP_GRAPH=1 (RCCL collectives captured in the step graph; hipvae.ddp.graph_capturable)
+    use_graph = not args.no_graph and (ddp.get() is None or ddp.graph_capturable())
     last = None
     for i in range(args.warmup):
         last = solver.train_step(batches[i % len(batches)], i)
@@ -192,6 +200,15 @@ def main():
         elapsed = time.perf_counter() - t0
         if rank == 0:
             log(f"graph: {args.steps} steps in {elapsed:.3f} s")
+    elif ddp.get() is not None:
+        # ---- timed region proper at N>1: K eager steps without the per-launch event pairs ----
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            last = solver.train_step(batches[i % len(batches)], args.warmup + args.steps + i)
+        sync()
+        elapsed = time.perf_counter() - t0
+        if rank == 0:
+            log(f"eager, events off: {args.steps} steps in {elapsed:.3f} s")
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -232,7 +249,8 @@ def main():
         "all_conv_kernels": {"achieved": round(conv_flop / conv_time * 1e-12, 2),
                              "share_of_eager_step_time": round(conv_time / eager_elapsed, 3)},
         "measured": f"HIP event pairs stamped at kernel start/end (hipExtLaunchKernelGGL inside libitcv_hip.so, launch stream) for every main conv kernel during {args.steps} eager steps of this workload, same process; they include the end-of-kernel L2 write-back of the result (about output bytes / 5 TB/s), which rocprofv3's dispatch timestamps in profiles/r01_final_kernel_stats.csv do not (5-20 % shorter there)"
-                    + (", immediately before the timed hipGraph-replay steps" if use_graph else " (the timed region)"),
+                    + (", immediately before the timed hipGraph-replay steps" if use_graph else
+                       ", immediately before the timed eager steps" if ddp.get() is not None else " (the timed region)"),
     }
 
     images = B_PER_GPU * world * args.steps
@@ -246,8 +264,8 @@ def main():
         "data": "synthetic",
         "config": {"workload": "c2: IntroTCSovler.train_step, conv arch, 64x64x3, z_dim=128, channels (64,128,256,512), "
                                f"batch {B_PER_GPU}/GPU, Adam lr 2e-4, clip 100, N=10000",
-                   "global_batch": B_PER_GPU * world, "parallelism": f"dp{world}" if world > 1 else "single",
-                   "sync_bn": bool(world > 1 and args.sync_bn)},
+                   "global_batch": B_PER_GPU * world, "parallelism": f"dp{world}" if world > 1 else ("single, dp code path forced (one-rank RCCL group)" if force_ddp else "single"),
+                   "sync_bn": bool(ddp.get() is not None and args.sync_bn)},
         "execution": "hipGraph replay (whole step = one graph)" if use_graph else "eager launches",
         "eager_ms_per_step": round(eager_elapsed / args.steps * 1e3, 3),
         "step_tflop": round(STEP_GFLOP_PER_IMAGE * B_PER_GPU * world * 1e-3, 3),
@@ -260,7 +278,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline()
             out["gpu_over_cpu"] = round(value / out["cpu_baseline"]["value"], 1)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if world > 1 or force_ddp:
         dist.barrier()
         dist.destroy_process_group()
 

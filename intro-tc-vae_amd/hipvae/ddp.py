@@ -118,6 +118,17 @@ def average_async(flat):
     return work.wait
 
 
+def graph_capturable():
+    """Whether a data-parallel step may be captured into a hipGraph: RCCL collectives are stream-ordered kernels and
+    capture like any other launch (every rank captures at the same step and replays in lock-step); gloo stages
+    through the host and cannot.  Opt-in (``ITCV_DDP_GRAPH=1``) until it has been timed on a multi-GPU node: the
+    one-GPU development box only reaches a group of one rank (tests/test_ddp.py)."""
+    import os
+    c = get()
+    return (c is not None and dist.get_backend(c.group) == "nccl"
+            and os.environ.get("ITCV_DDP_GRAPH", "0") == "1")
+
+
 def mean_scalars_(vec):
     """Average a small vector of per-rank loss scalars so every rank reports the global value."""
     c = get()

@@ -128,15 +128,17 @@ class VAESolver:
     def enable_graph(self, flag: bool = True):
         """Capture the whole training step (every kernel of both phases, the optimiser tail and the
         RNG draws) into ONE hipGraph after a few eager warm-up steps and replay it per step: the
-        ~1.7 k launches of a step then cost one submission.  Used single-rank, without a writer,
-        with device-side noise; anything else silently runs eagerly."""
+        ~1.4 k launches of a step then cost one submission.  Used without a writer, with device-side noise, and
+        single-rank unless ``ddp.graph_capturable()`` (RCCL collectives captured in the graph; opt-in, see there);
+        anything else silently runs eagerly."""
         self._graph_on = bool(flag)
         self._graph = None
         return self
 
     def _graph_ok(self):
         import ops
-        return (getattr(self, "_graph_on", False) and self.writer is None and ddp.get() is None
+        return (getattr(self, "_graph_on", False) and self.writer is None
+                and (ddp.get() is None or ddp.graph_capturable())
                 and ops._noise["queue"] is None and ops._noise["mode"] == "device"
                 and plain_adam_hparams(self.optimizer_e) is not None and plain_adam_hparams(self.optimizer_d) is not None)
 

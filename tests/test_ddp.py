@@ -167,3 +167,52 @@ def test_ddp_step_through_rccl_single_rank():
     for s in range(2):
         np.testing.assert_allclose(res[0]["res"][s], g[f"intro_tc:s{s}:dict"], rtol=1e-4 if s == 0 else 1e-3)
     assert res[0]["max"] <= 2.05 * 2e-4 * 2 and res[0]["frac"] < 5e-3 and res[0]["run"] < 1e-3
+
+
+def _graph_worker(rank, world, port, out):
+    os.environ["ITCV_DDP_GRAPH"] = "1"
+    _setup(rank, world, port, "nccl")
+    import models
+    from hipvae import ddp
+    from solvers.intro_tc import IntroTCSovler
+    dev = torch.device("cuda:0")
+
+    class DS:
+        def __len__(self):
+            return 1000
+
+    def run(graph, forced):
+        ddp.init(sync_bn=True, force=forced)
+        torch.manual_seed(3)
+        model = models.SoftIntroVAE(arch="conv", cdim=3, zdim=10, channels=(8, 16, 32), image_size=32).to(dev).train()
+        solver = IntroTCSovler(DS(), model, 8, torch.optim.Adam(model.encoder.parameters(), lr=2e-4),
+                               torch.optim.Adam(model.decoder.parameters(), lr=2e-4), "mse", 1.0, 1.0, 256.0, 1e-8,
+                               dev, False, None, clip=100.0)
+        if graph:
+            solver.enable_graph()
+        torch.manual_seed(5)
+        xs = [torch.rand(8, 3, 32, 32).to(dev) for _ in range(6)]
+        res = [solver.train_step(x, i) for i, x in enumerate(xs)]
+        captured = getattr(solver, "_graph", None) is not None
+        ddp.shutdown()
+        return res, captured, torch.cat([p.detach().reshape(-1) for p in model.parameters()]).cpu()
+
+    eager, cap_e, p_e = run(False, True)
+    graph, cap_g, p_g = run(True, True)
+    out[rank] = dict(cap_e=cap_e, cap_g=cap_g, eager=[list(d.values()) for d in eager],
+                     graph=[list(d.values()) for d in graph], pdiff=float((p_e - p_g).abs().max()))
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_ddp_step_graph_capture_with_rccl():
+    """ITCV_DDP_GRAPH=1: the data-parallel step (RCCL all-reduces, all-gather / reduce-scatter, Sync-BN moments, the
+    deferred gradient average) captured into the step hipGraph and replayed equals the eager data-parallel step."""
+    port = _free_port()
+    with mp.Manager() as m:
+        out = m.dict()
+        mp.spawn(_graph_worker, args=(1, port, out), nprocs=1, join=True)
+        r = dict(out)[0]
+    assert r["cap_g"] and not r["cap_e"]
+    np.testing.assert_allclose(np.array(r["graph"], dtype=np.float64), np.array(r["eager"], dtype=np.float64), rtol=2e-4)
+    assert r["pdiff"] < 1e-5
