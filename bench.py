@@ -1,30 +1,39 @@
 #!/usr/bin/env python3
 """Headline benchmark: images/sec of one IntroTCSovler.train_step (Soft-Intro beta-TC-VAE step:
-5 encoder + 8 decoder forwards, 2 backwards, 2 Adam updates) on synthetic 64x64x3 batches,
-z_dim=128, batch 64 per GPU, conv architecture -- BASELINE.json configs[1] (c2).  fp32 tensors; the conv
-products run in the mode --math selects (default bf16x3 = what the reference's use_amp=True config maps to).
+5 encoder + 8 decoder forwards, 2 backwards, 2 Adam updates) on synthetic batches resident in HBM.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config c2|c3|c5] [--math bf16x3|bf16x6|fp32]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
 
-One process per GPU; N>1 shards the batch (weak scaling, 64 images per GPU) with a flat RCCL
-all-reduce of the trained half's gradients per phase and an all-gather of mu for the full-batch TC
-estimator; BatchNorm statistics are per rank (throughput mode) unless --sync-bn (parity mode).  Rank 0 prints ONE JSON line.  Inputs are resident in HBM before
-the timed region; the timed region is bracketed by barrier + synchronize on both sides and the
-maximum over ranks is reported.  N=1 times K hipGraph replays of the whole step.  N>1 times K eager steps, then K
-replays of the captured data-parallel step (RCCL collectives inside the graph) under a watchdog that falls back to
-the finished eager measurement, and reports the faster execution (see _guarded_graph_leg; ITCV_DDP_GRAPH=0 skips it).
+Workloads (BASELINE.json configs; conv architecture, Adam lr 2e-4, clip 100, N = 10000):
+    c2 (default)  64x64x3,  z=128, channels (64,128,256,512),         64 images per GPU   -- the metric's configuration;
+                  with --gpus 8 this is BASELINE configs[3] (c4: global batch 512)
+    c3            128x128x3, z=256, channels (64,128,256,512,512),     128 images per GPU
+    c5            256x256x3, z=512, channels (64,128,256,512,512,512), 32 images per GPU  (--gpus 8: global batch 256)
+fp32 tensors throughout; the conv products run in the mode --math selects (default bf16x3 = what the reference's
+use_amp=True config maps to).  At N=1 on c2 the line also carries "modes": the same measurement in exact fp32 (the
+reference's own precision) and bf16x6, made in the same process.
+
+One process per GPU; N>1 shards the batch (weak scaling) with a flat RCCL all-reduce of the trained half's gradients
+per phase and an all-gather of mu for the full-batch TC estimator; BatchNorm statistics are per rank (throughput
+mode) unless --sync-bn (parity mode).  Rank 0 prints ONE JSON line.  The timed region is bracketed by barrier +
+synchronize on both sides and the maximum over ranks is reported.  N=1 times K hipGraph replays of the whole step.
+N>1 times K eager steps, then K replays of the captured data-parallel step (RCCL collectives inside the graph) under
+a watchdog that falls back to the finished eager measurement and says so in "graph_leg" (ITCV_DDP_GRAPH=0 skips it).
 
 Extra objects on the line:
-  roofline      dominant kernel (an implicit-GEMM conv on the matrix cores): algorithmic FLOP of its
-                launches / their HIP-event durations, measured live on the launch stream; peak = dense
-                MFMA peak of the arithmetic (2500/3 TFLOP/s for bf16x3, 157.3 for fp32; MI355X_MICROARCH.md).
-  cpu_baseline  the CPU oracle (oracle/, a PyTorch-CPU port pinned to the reference by golden
-                vectors) timed on the host cores on a bounded sample of the same workload.
+  roofline      dominant kernel (an implicit-GEMM conv on the matrix cores): algorithmic FLOP of its launches / their
+                HIP-event durations, measured live on the launch stream; peak = dense MFMA peak of the arithmetic
+                (2500/3 TFLOP/s for bf16x3, 2500/6 for bf16x6, 157.3 for fp32; MI355X_MICROARCH.md); traffic = HBM
+                bytes per launch from the committed rocprofv3 --pmc passes, only while the kernel sources are unchanged.
+  cpu_baseline  the CPU oracle (oracle/, a PyTorch-CPU port pinned to the reference by golden vectors) timed on the
+                host cores: 1 warm-up + 3 timed steps (BASELINE.md protocol) on a bounded batch of the same workload.
 """
 import argparse
 import contextlib
+import hashlib
+import io
 import json
 import os
 import sys
@@ -38,18 +47,37 @@ for p in (os.path.join(ROOT, "intro-tc-vae_amd"), ROOT):
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
-CFG = dict(cdim=3, zdim=128, channels=(64, 128, 256, 512), image_size=64)
-B_PER_GPU = 64
+# 13*Fe + 19*Fd GFLOP per image per intro-tc step (2*MAC, conv + linear)
+CONFIGS = {
+    "c2": dict(cfg=dict(cdim=3, zdim=128, channels=(64, 128, 256, 512), image_size=64), batch=64, gflop=48.237, cpu_batch=64,
+               metric="images/sec (64x64x3, z=128, bs=64) intro-TC step"),
+    "c3": dict(cfg=dict(cdim=3, zdim=256, channels=(64, 128, 256, 512, 512), image_size=128), batch=128, gflop=197.589,
+               cpu_batch=16, metric="images/sec (128x128x3, z=256, bs=128) intro-TC step"),
+    "c5": dict(cfg=dict(cdim=3, zdim=512, channels=(64, 128, 256, 512, 512, 512), image_size=256), batch=32, gflop=794.812,
+               cpu_batch=4, metric="images/sec (256x256x3, z=512, bs=32/GPU) intro-TC step"),
+}
 HP = dict(beta_kl=0.5, beta_rec=0.75, beta_neg=512.0, gamma_r=1e-8, clip=100.0, lr=2e-4, dataset=10000)
 PEAK_F32_MFMA_TFLOPS = 157.3
 PEAK_BF16_MFMA_TFLOPS = 2500.0       # dense; a split product costs 3 (bf16x3) or 6 (bf16x6) bf16 MFMA products
-# 13*Fe + 19*Fd = 48.237 GFLOP per image per intro-tc step (2*MAC, conv+linear)
-STEP_GFLOP_PER_IMAGE = 48.237
+PMC_FILE = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+DTYPE = {"fp32": "f32", "bf16x3": "f32 in/out/accumulate, conv products on split-bf16 MFMA (bf16x3)",
+         "bf16x6": "f32 in/out/accumulate, conv products on split-bf16 MFMA (bf16x6, fp32-class)"}
 
 
 class _DS:
     def __len__(self):
         return HP["dataset"]
+
+
+def csrc_digest():
+    """sha256 over the kernel sources: the PMC traffic figures are valid for exactly these."""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "intro-tc-vae_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".h")):
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()
 
 
 def host_cores():
@@ -70,38 +98,155 @@ def log(msg):
     print(f"[bench] {msg}", file=sys.stderr, flush=True)
 
 
-def cpu_baseline():
-    """Times the CPU oracle's intro-TC step on this host: a B=16 warm-up step, then ONE timed
-    step at the full B=64 (about 10-20 s of CPU work on 8-16 cores)."""
+def quiet_model(cfg):
     import models
+    with contextlib.redirect_stdout(io.StringIO()):       # the reference prints the conv shape at construction
+        return models.SoftIntroVAE(arch="conv", **cfg)
+
+
+def cpu_baseline(wl):
+    """Times the CPU oracle's intro-TC step on this host: 1 warm-up + 3 timed steps at ``cpu_batch``
+    images (the full per-GPU batch for c2; a bounded sample of it for the larger workloads)."""
     from oracle.network import Net
     from oracle.steps import Trainer
+    cfg, B = wl["cfg"], wl["cpu_batch"]
     cores = host_cores()
     torch.set_num_threads(cores)
     log(f"cpu baseline on {cores} threads (os.cpu_count()={os.cpu_count()})")
     torch.manual_seed(0)
-    import contextlib
-    import io
-    with contextlib.redirect_stdout(io.StringIO()):
-        model = models.SoftIntroVAE(arch="conv", **CFG)
-    state = {k: v.clone() for k, v in model.state_dict().items()}
-    tr = Trainer("intro_tc", Net("conv", state=state, **CFG), dataset_size=HP["dataset"], beta_kl=HP["beta_kl"],
+    state = {k: v.clone() for k, v in quiet_model(cfg).state_dict().items()}
+    tr = Trainer("intro_tc", Net("conv", state=state, **cfg), dataset_size=HP["dataset"], beta_kl=HP["beta_kl"],
                  beta_rec=HP["beta_rec"], beta_neg=HP["beta_neg"], gamma_r=HP["gamma_r"], clip=HP["clip"], lr=HP["lr"])
     g = torch.Generator().manual_seed(1234)
 
-    def one(batch):
-        x = torch.rand(batch, 3, 64, 64, generator=g)
-        draws = [torch.randn(batch, CFG["zdim"], generator=g) for _ in range(6)]
+    def one():
+        x = torch.rand(B, 3, cfg["image_size"], cfg["image_size"], generator=g)
+        draws = [torch.randn(B, cfg["zdim"], generator=g) for _ in range(6)]
         t0 = time.perf_counter()
         tr.step(x, draws)
         return time.perf_counter() - t0
 
-    log(f"cpu warm-up step B=16: {one(16):.1f} s")
-    t = one(B_PER_GPU)
-    log(f"cpu timed step B={B_PER_GPU}: {t:.1f} s")
-    return {"value": round(B_PER_GPU / t, 3), "unit": "images/s", "cores": cores, "kind": "port",
-            "sample": f"1 intro-tc step at B={B_PER_GPU} ({t:.1f} s) after a B=16 warm-up step; "
+    log(f"cpu warm-up step B={B}: {one():.1f} s")
+    ts = [one() for _ in range(3)]
+    log(f"cpu timed steps B={B}: " + ", ".join(f"{t:.1f} s" for t in ts))
+    return {"value": round(3 * B / sum(ts), 3), "unit": "images/s", "cores": cores, "kind": "port",
+            "step_seconds": [round(t, 2) for t in ts],
+            "sample": f"3 timed intro-tc steps at B={B} after 1 warm-up step (BASELINE.md protocol); "
                       "oracle/ (PyTorch-CPU fp32 port of the reference step, pinned by golden vectors)"}
+
+
+def make_solver(wl, math, dev):
+    from solvers.intro_tc import IntroTCSovler
+    torch.manual_seed(0)
+    model = quiet_model(wl["cfg"]).to(dev).train()
+    opt_e = torch.optim.Adam(model.encoder.parameters(), lr=HP["lr"])
+    opt_d = torch.optim.Adam(model.decoder.parameters(), lr=HP["lr"])
+    solver = IntroTCSovler(_DS(), model, wl["batch"], opt_e, opt_d, "mse", HP["beta_kl"], HP["beta_rec"],
+                           HP["beta_neg"], HP["gamma_r"], dev, math != "fp32", None, clip=HP["clip"])
+    solver.conv_math = math
+    return solver
+
+
+def roofline_of(records, math, steps, eager_elapsed, where):
+    """Dominant-kernel roofline from the live HIP-event records of the eager leg."""
+    buckets = {}
+    for label, flop, secs in records:
+        b = buckets.setdefault(label, [0, 0.0, 0.0])
+        b[0] += 1
+        b[1] += flop
+        b[2] += secs
+    conv_time = sum(b[2] for b in buckets.values())
+    conv_flop = sum(b[1] for b in buckets.values())
+    dom_label, dom = max(buckets.items(), key=lambda kv: kv[1][2])
+    achieved = dom[1] / dom[2] * 1e-12
+    if "bf16s" in dom_label or "bf16p" in dom_label:
+        products = 3 if "NS=2" in dom_label else 6
+        peak, peak_note = PEAK_BF16_MFMA_TFLOPS / products, f"2500 TFLOP/s dense bf16 MFMA / {products} bf16 products per fp32 product"
+    else:
+        peak, peak_note = PEAK_F32_MFMA_TFLOPS, "dense fp32 MFMA"
+    traffic, traffic_note = None, "no PMC record for this kernel / arithmetic"
+    try:   # HBM bytes per launch from the committed rocprofv3 --pmc passes over this same command (tools/pmc_summary.py)
+        pmc = json.load(open(PMC_FILE))
+        rec = pmc["kernels"].get(dom_label) if math == pmc.get("math") else None
+        if rec and pmc.get("csrc_sha256") != csrc_digest():
+            traffic_note = ("stale: the kernel sources changed since profiles/r02_pmc_traffic.json was collected "
+                            "(csrc_sha256 differs) -- re-run the --pmc passes")
+        elif rec:
+            traffic = rec["hbm_bytes_per_launch_fetch_x2"]
+            traffic_note = (f"{os.path.relpath(PMC_FILE, ROOT)}: (2*FETCH_SIZE + WRITE_SIZE)*1024 per launch, rocprofv3 --pmc, "
+                            f"separate passes, same kernel sources (csrc_sha256); raw (uncorrected) = {rec['hbm_bytes_per_launch_raw']}; "
+                            "algorithmic operand + result bytes per launch: B*H*W*(4*Ci + 4*Co) + packed weights (DESIGN.md section 6)")
+    except Exception:  # noqa: BLE001
+        pass
+    return {
+        "bound": "mfma", "kernel": dom_label, "achieved": round(achieved, 2), "peak": round(peak, 1),
+        "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_note": traffic_note,
+        "peak_note": peak_note, "launches_per_step": dom[0] / steps, "avg_launch_us": round(dom[2] / dom[0] * 1e6, 2),
+        "algorithmic_gflop_per_launch": round(dom[1] / dom[0] * 1e-9, 3),
+        "all_conv_kernels": {"achieved": round(conv_flop / conv_time * 1e-12, 2),
+                             "share_of_eager_step_time": round(conv_time / eager_elapsed, 3)},
+        "measured": "HIP event pairs stamped at kernel start/end (hipExtLaunchKernelGGL inside libitcv_hip.so, launch "
+                    f"stream) for every main conv kernel during {steps} eager steps of this workload, same process; they "
+                    "include the end-of-kernel L2 write-back of the result, which rocprofv3's dispatch timestamps do not "
+                    "(5-20 % shorter there)" + where,
+    }
+
+
+def measure(wl, math, dev, args, rank, world, sync, use_graph, ddp_on):
+    """Warm-up, roofline leg (K eager steps with per-launch events), timed leg.  Returns a dict of raw results."""
+    from hipvae import functional as HF
+    solver = make_solver(wl, math, dev)
+    B, S = wl["batch"], wl["cfg"]["image_size"]
+    g = torch.Generator().manual_seed(1000 + rank)
+    batches = [torch.rand(B, 3, S, S, generator=g).to(dev) for _ in range(4)]   # resident in HBM
+    last = None
+    for i in range(args.warmup):
+        last = solver.train_step(batches[i % len(batches)], i)
+        if rank == 0:
+            log(f"[{math}] warm-up step {i}: {last}")
+    sync()
+    # ---- roofline leg: K eager steps with a HIP-event pair around every implicit-GEMM launch ----
+    HF.LaunchProfile.begin()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        last = solver.train_step(batches[i % len(batches)], args.warmup + i)
+    sync()
+    eager_elapsed = time.perf_counter() - t0
+    records = HF.LaunchProfile.end()
+    elapsed = eager_elapsed
+    if rank == 0:
+        log(f"[{math}] eager: {args.steps} steps in {eager_elapsed:.3f} s (events on)")
+    if use_graph:
+        # ---- timed region proper: the same K steps as hipGraph replays (one submission per step) ----
+        solver.enable_graph()
+        for i in range(5):                      # 3 eager warm-ups, capture + first replay, one more replay
+            last = solver.train_step(batches[i % len(batches)], 0)
+        assert solver._graph is not None
+        sync()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            last = solver.train_step(batches[i % len(batches)], args.warmup + args.steps + i)
+        sync()
+        elapsed = time.perf_counter() - t0
+        if rank == 0:
+            log(f"[{math}] graph: {args.steps} steps in {elapsed:.3f} s")
+    elif ddp_on:
+        # ---- timed region proper at N>1: K eager steps without the per-launch event pairs ----
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            last = solver.train_step(batches[i % len(batches)], args.warmup + args.steps + i)
+        sync()
+        elapsed = time.perf_counter() - t0
+        if rank == 0:
+            log(f"[{math}] eager, events off: {args.steps} steps in {elapsed:.3f} s")
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t)
+    where = (", immediately before the timed hipGraph-replay steps" if use_graph else
+             ", immediately before the timed eager steps" if ddp_on else " (the timed region)")
+    return dict(solver=solver, batches=batches, elapsed=elapsed, eager_elapsed=eager_elapsed, last=last,
+                roofline=roofline_of(records, math, args.steps, eager_elapsed, where))
 
 
 def main():
@@ -109,7 +254,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="c2",
+                    help="workload: c2 = the metric's configuration (c4 when --gpus 8); c3 / c5 = BASELINE configs[2] / [4]")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-modes", action="store_true",
+                    help="N=1, c2: skip the additional fp32 / bf16x6 measurements (the 'modes' object)")
     ap.add_argument("--sync-bn", action="store_true",
                     help="N>1: all-reduce BatchNorm moments (full-batch parity mode); default is per-rank statistics")
     ap.add_argument("--math", choices=["bf16x3", "bf16x6", "fp32"], default="bf16x3",
@@ -117,6 +266,7 @@ def main():
                          "MFMA with fp32 accumulate; bf16x6 = fp32-class 3-way split; fp32 = exact fp32 MFMA")
     ap.add_argument("--no-graph", action="store_true", help="time eager launches instead of hipGraph replays (N=1)")
     args = ap.parse_args()
+    wl = CONFIGS[args.config]
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -148,26 +298,10 @@ def main():
                 dist.init_process_group(backend)
             dist.barrier()
 
-    import contextlib
-    import io
-    import models
     from hipvae import ddp
-    from hipvae import functional as HF
-    from solvers.intro_tc import IntroTCSovler
 
     if world > 1 or force_ddp:
         ddp.init(sync_bn=args.sync_bn, force=force_ddp)
-    torch.manual_seed(0)
-    with contextlib.redirect_stdout(io.StringIO()):
-        model = models.SoftIntroVAE(arch="conv", **CFG)
-    model = model.to(dev).train()
-    opt_e = torch.optim.Adam(model.encoder.parameters(), lr=HP["lr"])
-    opt_d = torch.optim.Adam(model.decoder.parameters(), lr=HP["lr"])
-    solver = IntroTCSovler(_DS(), model, B_PER_GPU, opt_e, opt_d, "mse", HP["beta_kl"], HP["beta_rec"],
-                           HP["beta_neg"], HP["gamma_r"], dev, args.math != "fp32", None, clip=HP["clip"])
-    solver.conv_math = args.math
-    g = torch.Generator().manual_seed(1000 + rank)
-    batches = [torch.rand(B_PER_GPU, 3, 64, 64, generator=g).to(dev) for _ in range(4)]   # resident in HBM
 
     def sync():
         if world > 1:
@@ -175,128 +309,72 @@ def main():
         torch.cuda.synchronize()
 
     # N>1: eager unless ITCV_DDP_GRAPH=1 (RCCL collectives captured in the step graph; hipvae.ddp.graph_capturable)
-    use_graph = not args.no_graph and (ddp.get() is None or ddp.graph_capturable())
-    last = None
-    for i in range(args.warmup):
-        last = solver.train_step(batches[i % len(batches)], i)
-        if rank == 0:
-            log(f"warm-up step {i}: {last}")
-    sync()
-    # ---- roofline leg: K eager steps with a HIP-event pair around every implicit-GEMM launch ----
-    HF.LaunchProfile.begin()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        last = solver.train_step(batches[i % len(batches)], args.warmup + i)
-    sync()
-    eager_elapsed = time.perf_counter() - t0
-    records = HF.LaunchProfile.end()
-    elapsed = eager_elapsed
-    if rank == 0:
-        log(f"eager: {args.steps} steps in {eager_elapsed:.3f} s (events on)")
-    if use_graph:
-        # ---- timed region proper: the same K steps as hipGraph replays (one submission per step) ----
-        solver.enable_graph()
-        for i in range(5):                      # 3 eager warm-ups, capture + first replay, one more replay
-            last = solver.train_step(batches[i % len(batches)], 0)
-        assert solver._graph is not None
-        sync()
-        t0 = time.perf_counter()
-        for i in range(args.steps):
-            last = solver.train_step(batches[i % len(batches)], args.warmup + args.steps + i)
-        sync()
-        elapsed = time.perf_counter() - t0
-        if rank == 0:
-            log(f"graph: {args.steps} steps in {elapsed:.3f} s")
-    elif ddp.get() is not None:
-        # ---- timed region proper at N>1: K eager steps without the per-launch event pairs ----
-        t0 = time.perf_counter()
-        for i in range(args.steps):
-            last = solver.train_step(batches[i % len(batches)], args.warmup + args.steps + i)
-        sync()
-        elapsed = time.perf_counter() - t0
-        if rank == 0:
-            log(f"eager, events off: {args.steps} steps in {elapsed:.3f} s")
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t)
+    ddp_on = ddp.get() is not None
+    use_graph = not args.no_graph and (not ddp_on or ddp.graph_capturable())
+    B = wl["batch"]
+    m = measure(wl, args.math, dev, args, rank, world, sync, use_graph, ddp_on)
+    solver, batches, elapsed, eager_elapsed, last = m["solver"], m["batches"], m["elapsed"], m["eager_elapsed"], m["last"]
 
-    # ---- roofline of the dominant kernel from the live HIP-event records -------------------
-    buckets = {}
-    for label, flop, secs in records:
-        b = buckets.setdefault(label, [0, 0.0, 0.0])
-        b[0] += 1
-        b[1] += flop
-        b[2] += secs
-    conv_time = sum(b[2] for b in buckets.values())
-    conv_flop = sum(b[1] for b in buckets.values())
-    dom_label, dom = max(buckets.items(), key=lambda kv: kv[1][2])
-    achieved = dom[1] / dom[2] * 1e-12
-    if "bf16s" in dom_label or "bf16p" in dom_label:
-        products = 3 if "NS=2" in dom_label else 6
-        peak, peak_note = PEAK_BF16_MFMA_TFLOPS / products, f"2500 TFLOP/s dense bf16 MFMA / {products} bf16 products per fp32 product"
-    else:
-        peak, peak_note = PEAK_F32_MFMA_TFLOPS, "dense fp32 MFMA"
-    traffic, traffic_note = None, None
-    try:   # HBM bytes per launch from the committed rocprofv3 --pmc passes over this same command (tools/pmc_summary.py)
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
-        rec = pmc["kernels"].get(dom_label) if args.math == pmc.get("math") else None
-        if rec:
-            traffic = rec["hbm_bytes_per_launch_fetch_x2"]
-            traffic_note = ("profiles/r01_pmc_traffic.json: (2*FETCH_SIZE + WRITE_SIZE)*1024 per launch, rocprofv3 --pmc, "
-                            f"separate passes; raw (uncorrected) = {rec['hbm_bytes_per_launch_raw']}; algorithmic operand + "
-                            "result bytes per launch: B*H*W*(4*Ci + 4*Co) + packed weights (DESIGN.md section 6)")
-    except Exception:  # noqa: BLE001
-        pass
-    roofline = {
-        "bound": "mfma", "kernel": dom_label, "achieved": round(achieved, 2), "peak": round(peak, 1),
-        "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_note": traffic_note, "peak_note": peak_note,
-        "launches_per_step": dom[0] / args.steps, "avg_launch_us": round(dom[2] / dom[0] * 1e6, 2),
-        "algorithmic_gflop_per_launch": round(dom[1] / dom[0] * 1e-9, 3),
-        "all_conv_kernels": {"achieved": round(conv_flop / conv_time * 1e-12, 2),
-                             "share_of_eager_step_time": round(conv_time / eager_elapsed, 3)},
-        "measured": f"HIP event pairs stamped at kernel start/end (hipExtLaunchKernelGGL inside libitcv_hip.so, launch stream) for every main conv kernel during {args.steps} eager steps of this workload, same process; they include the end-of-kernel L2 write-back of the result (about output bytes / 5 TB/s), which rocprofv3's dispatch timestamps in profiles/r01_final_kernel_stats.csv do not (5-20 % shorter there)"
-                    + (", immediately before the timed hipGraph-replay steps" if use_graph else
-                       ", immediately before the timed eager steps" if ddp.get() is not None else " (the timed region)"),
-    }
-
-    images = B_PER_GPU * world * args.steps
+    images = B * world * args.steps
     value = images / elapsed
+    cfg = wl["cfg"]
     out = {
-        "metric": "images/sec (64x64x3, z=128, bs=64) intro-TC step", "value": round(value, 2), "unit": "images/s",
+        "metric": wl["metric"], "value": round(value, 2), "unit": "images/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": {"fp32": "f32", "bf16x3": "f32 in/out/accumulate, conv products on split-bf16 MFMA (bf16x3)",
-                  "bf16x6": "f32 in/out/accumulate, conv products on split-bf16 MFMA (bf16x6, fp32-class)"}[args.math],
-        "data": "synthetic",
-        "config": {"workload": "c2: IntroTCSovler.train_step, conv arch, 64x64x3, z_dim=128, channels (64,128,256,512), "
-                               f"batch {B_PER_GPU}/GPU, Adam lr 2e-4, clip 100, N=10000",
-                   "global_batch": B_PER_GPU * world, "parallelism": f"dp{world}" if world > 1 else ("single, dp code path forced (one-rank RCCL group)" if force_ddp else "single"),
-                   "sync_bn": bool(ddp.get() is not None and args.sync_bn)},
+        "dtype": DTYPE[args.math], "data": "synthetic",
+        "config": {"workload": f"{args.config}: IntroTCSovler.train_step, conv arch, {cfg['image_size']}x{cfg['image_size']}x3, "
+                               f"z_dim={cfg['zdim']}, channels {tuple(cfg['channels'])}, batch {B}/GPU, Adam lr 2e-4, clip 100, N=10000",
+                   "global_batch": B * world,
+                   "parallelism": f"dp{world}" if world > 1 else ("single, dp code path forced (one-rank RCCL group)" if force_ddp else "single"),
+                   "sync_bn": bool(ddp_on and args.sync_bn)},
         "execution": "hipGraph replay (whole step = one graph)" if use_graph else "eager launches",
         "eager_ms_per_step": round(eager_elapsed / args.steps * 1e3, 3),
-        "step_tflop": round(STEP_GFLOP_PER_IMAGE * B_PER_GPU * world * 1e-3, 3),
-        "whole_step_tflops": round(value * STEP_GFLOP_PER_IMAGE * 1e-3 / world, 2),
+        "step_tflop": round(wl["gflop"] * B * world * 1e-3, 3),
+        "whole_step_tflops": round(value * wl["gflop"] * 1e-3 / world, 2),
         "last_step": last,
-        "roofline": roofline,
+        "roofline": m["roofline"],
     }
     # ---- N>1 over RCCL: the same K steps once more with the data-parallel step captured into the step hipGraph ----
-    # The eager measurement above is complete and stays the fallback: a watchdog prints it and ends the process
-    # if the captured leg raises or makes no progress (ITCV_DDP_GRAPH=0 skips the attempt, =1 uses the graph for
-    # the main timed region instead).  The faster of the two executions is the reported one, named in "execution".
-    if (ddp.get() is not None and not use_graph and not args.no_graph and backend == "nccl"
+    # The eager measurement above is complete and stays the fallback: a watchdog prints it -- with
+    # "graph_leg": {"status": "abandoned", "reason": ...} -- and ends the process if the captured leg raises or makes no
+    # progress (ITCV_DDP_GRAPH=0 skips the attempt, =1 uses the graph for the main timed region instead).  The faster
+    # of the two executions is the reported one, named in "execution".
+    if (ddp_on and not use_graph and not args.no_graph and backend == "nccl"
             and os.environ.get("ITCV_DDP_GRAPH", "auto") == "auto"):
-        g_elapsed = _guarded_graph_leg(solver, batches, args, rank, sync, dev, json.dumps(out))
+        g_elapsed = _guarded_graph_leg(solver, batches, args, rank, sync, dev, out)
+        out["graph_leg"] = {"status": "ok", "ms_per_step": round(g_elapsed / args.steps * 1e3, 3)}
         out["eager_events_off_ms_per_step"] = out["ms_per_step"]
         out["graph_ms_per_step"] = round(g_elapsed / args.steps * 1e3, 3)
         if g_elapsed < elapsed:
             value = images / g_elapsed
             out.update(value=round(value, 2), ms_per_step=out["graph_ms_per_step"],
                        execution="hipGraph replay (whole data-parallel step, RCCL collectives included, = one graph per rank)",
-                       whole_step_tflops=round(value * STEP_GFLOP_PER_IMAGE * 1e-3 / world, 2))
+                       whole_step_tflops=round(value * wl["gflop"] * 1e-3 / world, 2))
+    elif ddp_on:
+        out["graph_leg"] = {"status": "skipped" if not use_graph else "main",
+                            "reason": "ITCV_DDP_GRAPH / --no-graph / backend" if not use_graph else "ITCV_DDP_GRAPH=1"}
+    # ---- N=1 on the metric's workload: the same measurement in the reference's own precision (and bf16x6) ----------
+    if world == 1 and not ddp_on and args.config == "c2" and not args.no_modes:
+        del solver, batches, m
+        torch.cuda.empty_cache()
+        out["modes"] = {}
+        for math in ("fp32", "bf16x6"):
+            if math == args.math:
+                continue
+            mm = measure(wl, math, dev, args, rank, world, sync, use_graph, ddp_on)
+            v = B * args.steps / mm["elapsed"]
+            r = mm["roofline"]
+            out["modes"][math] = {"value": round(v, 2), "unit": "images/s", "ms_per_step": round(mm["elapsed"] / args.steps * 1e3, 3),
+                                  "dtype": DTYPE[math], "whole_step_tflops": round(v * wl["gflop"] * 1e-3, 2),
+                                  "last_step": mm["last"],
+                                  "roofline": {k: r[k] for k in ("kernel", "achieved", "peak", "unit", "frac", "avg_launch_us",
+                                                                 "launches_per_step")}}
+            del mm
+            torch.cuda.empty_cache()
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline()
+            out["cpu_baseline"] = cpu_baseline(wl)
             out["gpu_over_cpu"] = round(value / out["cpu_baseline"]["value"], 1)
         print(json.dumps(out), flush=True)
     if world > 1 or force_ddp:
@@ -318,10 +396,12 @@ def _stdout_to_stderr():
         os.close(saved)
 
 
-def _guarded_graph_leg(solver, batches, args, rank, sync, dev, eager_line):
+def _guarded_graph_leg(solver, batches, args, rank, sync, dev, eager_out):
     """Capture the data-parallel step and time K replays (max over ranks).  Never returns on failure: on an exception
-    or when the deadline passes (a rank stuck in a collective), rank 0 prints ``eager_line`` -- the finished eager
-    measurement -- and every rank that notices ends its process with status 0."""
+    or when the deadline passes (a rank stuck in a collective), rank 0 prints the finished eager measurement
+    (``eager_out``) with "graph_leg": {"status": "abandoned", "reason": ...} added -- so the record shows that the
+    captured leg did not complete and why -- and every rank that notices ends its process.  Nothing is re-executed and
+    no process is replaced: the eager numbers were complete before this leg started."""
     import threading
     deadline = float(os.environ.get("ITCV_BENCH_GRAPH_DEADLINE", "90"))
     lock, state = threading.Lock(), {"closed": False}
@@ -333,7 +413,9 @@ def _guarded_graph_leg(solver, batches, args, rank, sync, dev, eager_line):
             state["closed"] = True
         if rank == 0:
             log(f"captured data-parallel leg abandoned ({reason}); reporting the eager measurement")
-            print(eager_line, flush=True)
+            line = dict(eager_out)
+            line["graph_leg"] = {"status": "abandoned", "reason": str(reason)[:300], "deadline_s": deadline}
+            print(json.dumps(line), flush=True)
         sys.stderr.flush()
         os._exit(0)
 

@@ -28,6 +28,25 @@
 
 namespace itcv {
 
+// Diagnostic instrumentation (operand ablation, in-kernel cycle stamps) exists only in -DITCV_DIAG builds
+// (`make diag`, used by tools/abl.sh): in the shipped library the tests below are the constant 0, the branches are
+// compiled out and no environment variable can alter results.
+#ifdef ITCV_DIAG
+#define ITCV_ABL(args, bits) (((args).ablate & (bits)) != 0)
+#define ITCV_DBG(args) ((args).debug != 0)
+static int diag_ablate() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("ITCV_ABLATE");
+    v = e ? atoi(e) : 0;
+  }
+  return v;
+}
+#else
+#define ITCV_ABL(args, bits) (false)
+#define ITCV_DBG(args) (false)
+#endif
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -379,7 +398,9 @@ struct ConvArgsB {
   int ktiles, ktiles_per_split, cpt;  // cpt = K-tiles per tap = Cip/32
   uint32_t x_bytes;
   size_t slab_stride;
+#ifdef ITCV_DIAG
   int ablate;  // diagnostic only (ITCV_ABLATE): 1 no gathers, 2 no split, 4 no weight DMA, 8 no MFMA, 16 no B stores
+#endif
 };
 
 template <int KS, int BM, int BN, int WM, int WN, bool UP2, int NS>
@@ -628,7 +649,7 @@ __global__ __launch_bounds__(512) void conv_fwd_bf16s_ws_kernel(ConvArgsB a) {
       else
         off = tb + dh * W + dw + cib * BK * HWs;
       const uint32_t voff = valid ? (uint32_t)off * 4u : kOobBase;
-      if (a.ablate & 1) {
+      if ITCV_ABL(a, 1) {
 #pragma unroll
         for (int i = 0; i < RPT; ++i) dst[i] = __builtin_bit_cast(float, voff + i);
         return;
@@ -644,7 +665,7 @@ __global__ __launch_bounds__(512) void conv_fwd_bf16s_ws_kernel(ConvArgsB a) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] = src[c * 8 + j];
         u32x4 pl[NS];
-        if (a.ablate & 2) {
+        if ITCV_ABL(a, 2) {
 #pragma unroll
           for (int pp = 0; pp < NS; ++pp)
             pl[pp] = u32x4{__builtin_bit_cast(unsigned, v[pp]), __builtin_bit_cast(unsigned, v[2 + pp]),
@@ -653,7 +674,7 @@ __global__ __launch_bounds__(512) void conv_fwd_bf16s_ws_kernel(ConvArgsB a) {
           split8<NS>(v, pl);
         }
         const int kc = kg * (RPT / 8) + c;
-        if (a.ablate & 16) {
+        if ITCV_ABL(a, 16) {
           asm volatile("" ::"v"(pl[0][0]), "v"(pl[NS - 1][3]));
           continue;
         }
@@ -704,7 +725,7 @@ __global__ __launch_bounds__(512) void conv_fwd_bf16s_ws_kernel(ConvArgsB a) {
   constexpr int AL = ASZ / NP;
   static_assert(ASZ % NP == 0, "A tile chunks must divide evenly");
   auto dma_A = [&](int kt, int buf) {
-    if (a.ablate & 4) return;
+    if ITCV_ABL(a, 4) return;
     const u32x4* wt = a.wp + (size_t)kt * NS * KC * a.Mp;
 #pragma unroll
     for (int i = 0; i < AL; ++i) {
@@ -730,7 +751,7 @@ __global__ __launch_bounds__(512) void conv_fwd_bf16s_ws_kernel(ConvArgsB a) {
     const u32x4* Bb = Bs + cur * BSZ;
 #pragma unroll
     for (int ks = 0; ks < BK / 16; ++ks) {
-      if (a.ablate & 8) break;
+      if ITCV_ABL(a, 8) break;
       const int kc = ks * 2 + half;
       bf16x8 af[NS][TM], bfr[NS][TN];
 #pragma unroll
@@ -778,7 +799,7 @@ __global__ __launch_bounds__(512) void conv_fwd_bf16s_ws_kernel(ConvArgsB a) {
         if (m < a.Co) {
           float v = acc[i][j][r];
           if (a.bias) v += a.bias[m];
-          if ((a.ablate & 32) && v != 12345.f) continue;
+          if (ITCV_ABL(a, 32) && v != 12345.f) continue;
           out[base + (size_t)m * HW] = v;
         }
       }
@@ -807,7 +828,9 @@ struct ConvArgsP {
   int ktiles, ktiles_per_split;
   size_t slab_stride;
   size_t plane_stride;   // chunks per plane = B * (Ci/8) * Hs * Ws
+#ifdef ITCV_DIAG
   int ablate;            // diagnostic only (ITCV_ABLATE): 1 no B pieces, 4 no A pieces, 8 no MFMA
+#endif
 };
 
 template <int KS, int BM, int BN, int WM, int WN, bool UP2, int NS, int NSTAGE>
@@ -870,13 +893,13 @@ __global__ __launch_bounds__(512) void conv_fwd_bf16p_kernel(ConvArgsP a) {
       const u32x4* wt = a.wp + (size_t)kt * NS * KC * a.Mp + m0 + lane;
 #pragma unroll
       for (int j = 0; j < PA; ++j) {
-        if (a.ablate & 4) break;
+        if ITCV_ABL(a, 4) break;
         const int piece = j * 4 + lw, mlc = piece % NPA, pk = piece / NPA;
         lds_dma16(wt + (size_t)pk * a.Mp + mlc * 64, sbase + (uint32_t)(pk * BM + mlc * 64) * 16u);
       }
 #pragma unroll
       for (int j = 0; j < PB; ++j) {
-        if (a.ablate & 1) break;
+        if ITCV_ABL(a, 1) break;
         const int piece = j * 4 + lw, pk = piece / NPB, pl = pk / KC, kc = pk - pl * KC;
         const u32x4* src = src0 + ((size_t)pl * a.plane_stride + (size_t)kc * HWs);
         lds_dma16(valid ? src : zero, sbase + (uint32_t)(ASZ + pk * BN + nlc * 64) * 16u);
@@ -908,11 +931,11 @@ __global__ __launch_bounds__(512) void conv_fwd_bf16p_kernel(ConvArgsP a) {
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
   __builtin_amdgcn_s_barrier();
   int slot = 0;
-  const long long dbg_c0 = (a.ablate & 64) ? clock64() : 0, dbg_w0 = (a.ablate & 64) ? wall_clock64() : 0;
+  const long long dbg_c0 = ITCV_ABL(a, 64) ? clock64() : 0, dbg_w0 = ITCV_ABL(a, 64) ? wall_clock64() : 0;
   for (int it = 0; it < nk; ++it) {
     const u32x4* Ab = smem + slot * SSZ;
     const u32x4* Bb = Ab + ASZ;
-    if (!(a.ablate & 8)) {
+    if (!ITCV_ABL(a, 8)) {
       // both k-steps' fragments requested up front, reads interleaved behind the MFMAs (see conv_fwd_bf16p2_kernel)
       bf16x8 af[2][NS][TM], bfr[2][NS][TN];
 #pragma unroll
@@ -960,7 +983,7 @@ __global__ __launch_bounds__(512) void conv_fwd_bf16p_kernel(ConvArgsP a) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this tile's fragments are in registers
     __builtin_amdgcn_s_barrier();
   }
-  if ((a.ablate & 64) && t == 0 && (bid == 0 || bid == 300)) {   // diagnostic: main-loop shader cycles / 100 MHz ticks
+  if (ITCV_ABL(a, 64) && t == 0 && (bid == 0 || bid == 300)) {   // diagnostic: main-loop shader cycles / 100 MHz ticks
     a.y[(bid ? 2 : 0) + 0] = (float)(clock64() - dbg_c0);
     a.y[(bid ? 2 : 0) + 1] = (float)(wall_clock64() - dbg_w0);
     return;
@@ -1010,7 +1033,9 @@ struct ConvArgsP2 {
   int SR, NSEG, NP, NPC, PXB;    // band geometry: segment rows, segments, halo pixels, 64-chunk pieces, LDS row stride
   int h_shift;
   size_t slab_stride, plane_stride;
+#ifdef ITCV_DIAG
   int debug;   // diagnostic only (ITCV_ABLATE & 64): block 0 / 100 report main-loop shader cycles and 100 MHz ticks in y[0..3]
+#endif
 };
 
 template <int LOG2W, int BM, bool UP2>
@@ -1148,10 +1173,10 @@ __global__ __launch_bounds__(768) void conv_fwd_bf16p2_kernel(ConvArgsP2 a) {
     for (int j = 0; j < TN; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-  const long long dbg_c00 = a.debug ? clock64() : 0;
+  const long long dbg_c00 = ITCV_DBG(a) ? clock64() : 0;
   __builtin_amdgcn_s_barrier();
   int buf = 0;
-  const long long dbg_c0 = a.debug ? clock64() : 0, dbg_w0 = a.debug ? wall_clock64() : 0;
+  const long long dbg_c0 = ITCV_DBG(a) ? clock64() : 0, dbg_w0 = ITCV_DBG(a) ? wall_clock64() : 0;
   int slot = 0;
   for (int cib = c0; cib < c1; ++cib) {
     const uint32_t bb = band_base + (uint32_t)(buf * BSZ) * 16u;
@@ -1211,7 +1236,7 @@ __global__ __launch_bounds__(768) void conv_fwd_bf16p2_kernel(ConvArgsP2 a) {
     }
     buf ^= 1;
   }
-  if (a.debug && t == 0 && (bid == 0 || bid == 100)) {
+  if (ITCV_DBG(a) && t == 0 && (bid == 0 || bid == 100)) {
     float* d = a.y + (bid ? 4 : 0);
     d[0] = (float)(clock64() - dbg_c0), d[1] = (float)(wall_clock64() - dbg_w0), d[2] = (float)(dbg_c0 - dbg_c00), d[3] = (float)nk;
     return;
@@ -1635,7 +1660,9 @@ struct WgradArgsP {
   int steps, steps_per_split, splits;
   int h_shift;
   size_t xplane, dyplane;   // chunks per plane
+#ifdef ITCV_DIAG
   int debug;                // diagnostic only (ITCV_ABLATE & 64): block 0 reports main-loop shader cycles / steps in slab[0..1]
+#endif
 };
 
 __device__ __forceinline__ void tr_read8(bf16x8& dst, uint32_t addr0, uint32_t addr1) {
@@ -1764,7 +1791,7 @@ __global__ __launch_bounds__(512 + 64 * NLW) void conv_wgrad_bf16p_kernel(WgradA
     }
     __builtin_amdgcn_s_barrier();
     int stage = 0;
-    const long long dbg_c0 = a.debug ? clock64() : 0;
+    const long long dbg_c0 = ITCV_DBG(a) ? clock64() : 0;
     for (int st = s0; st < s1; ++st) {
       const uint32_t sb = smem_base + (uint32_t)(stage * SSZ) * 16u;
       if constexpr (TNw == 1) {
@@ -1842,7 +1869,7 @@ __global__ __launch_bounds__(512 + 64 * NLW) void conv_wgrad_bf16p_kernel(WgradA
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
     }
-    if (a.debug && t == 0 && blockIdx.x == 0) {
+    if (ITCV_DBG(a) && t == 0 && blockIdx.x == 0) {
       a.slab[0] = (float)(clock64() - dbg_c0), a.slab[1] = (float)(s1 - s0);
       return;
     }
@@ -2639,14 +2666,9 @@ int itcv_conv2d_fwd_bf16s(const float* x, const void* wp, const float* bias, flo
   a.mt = p.mt, a.nt = p.nt, a.ktiles = p.ktiles, a.ktiles_per_split = p.kps, a.cpt = p.cip / 32;
   a.x_bytes = (uint32_t)((size_t)B * Ci * (up2 ? (H / 2) * (W / 2) : H * W) * sizeof(float));
   a.slab_stride = p.splits > 1 ? out_elems : 0;
-  {
-    static int abl = -1;
-    if (abl < 0) {
-      const char* e = getenv("ITCV_ABLATE");
-      abl = e ? atoi(e) : 0;
-    }
-    a.ablate = abl;
-  }
+#ifdef ITCV_DIAG
+  a.ablate = diag_ablate();
+#endif
   hipStream_t st = S(stream);
   {
     ProfScope prof(st, 1, KS, p.bm, up2 ? 1 : 0, ns, 2.0 * B * H * W * (double)Co * Ci * KS * KS);
@@ -2715,14 +2737,9 @@ int itcv_conv2d_fwd_bf16p(const void* xplanes, const void* wp, const float* bias
     a.h_shift = log2_exact(H);
     a.slab_stride = p2.splits > 1 ? out_elems : 0;
     a.plane_stride = (size_t)B * (Ci / 8) * (up2 ? (H / 2) * (W / 2) : H * W);
-    {
-      static int dbg = -1;
-      if (dbg < 0) {
-        const char* e = getenv("ITCV_ABLATE");
-        dbg = (e && (atoi(e) & 64)) ? 1 : 0;
-      }
-      a.debug = dbg;
-    }
+#ifdef ITCV_DIAG
+    a.debug = (diag_ablate() & 64) ? 1 : 0;
+#endif
     hipStream_t st = S(stream);
     {
       ProfScope prof(st, 8, log2_exact(W), p2.bm, up2 ? 1 : 0, ns, 2.0 * B * H * W * (double)Co * Ci * KS * KS);
@@ -2757,14 +2774,9 @@ int itcv_conv2d_fwd_bf16p(const void* xplanes, const void* wp, const float* bias
   a.mt = p.mt, a.nt = p.nt, a.ktiles = p.ktiles, a.ktiles_per_split = p.kps;
   a.slab_stride = p.splits > 1 ? out_elems : 0;
   a.plane_stride = (size_t)B * (Ci / 8) * (up2 ? (H / 2) * (W / 2) : H * W);
-  {
-    static int abl = -1;
-    if (abl < 0) {
-      const char* e = getenv("ITCV_ABLATE");
-      abl = e ? atoi(e) : 0;
-    }
-    a.ablate = abl;
-  }
+#ifdef ITCV_DIAG
+  a.ablate = diag_ablate();
+#endif
   hipStream_t st = S(stream);
   {
     ProfScope prof(st, 6, KS, p.bm, up2 ? 1 : 0, ns, 2.0 * B * H * W * (double)Co * Ci * KS * KS);
@@ -2944,14 +2956,9 @@ int itcv_conv2d_wgrad_bf16p(const void* xplanes, const void* dyplanes, float* dw
   a.h_shift = log2_exact(H);
   a.xplane = (size_t)B * (Ci / 8) * (up2 ? (H / 2) * (W / 2) : H * W);
   a.dyplane = (size_t)B * (Co / 8) * H * W;
-  {
-    static int dbg = -1;
-    if (dbg < 0) {
-      const char* e = getenv("ITCV_ABLATE");
-      dbg = (e && (atoi(e) & 64)) ? 1 : 0;
-    }
-    a.debug = dbg;
-  }
+#ifdef ITCV_DIAG
+  a.debug = (diag_ablate() & 64) ? 1 : 0;
+#endif
   hipStream_t st = S(stream);
   const int blocks = p.tiles_m * p.tiles_n * 3 * p.splits;
   {

@@ -16,7 +16,8 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 PKG_ROOT = os.path.dirname(_HERE)
-LIB_PATH = os.path.join(PKG_ROOT, "lib", "libitcv_hip.so")
+# ITCV_LIB: load another build of the same library (the -DITCV_DIAG diagnostic build of `make diag`, tools/abl.sh)
+LIB_PATH = os.environ.get("ITCV_LIB") or os.path.join(PKG_ROOT, "lib", "libitcv_hip.so")
 CSRC = os.path.join(PKG_ROOT, "csrc")
 ABI_VERSION = 1
 

@@ -15,7 +15,10 @@ F32 = torch.float32
 
 
 class FlatGroup:
-    def __init__(self, params):
+    def __init__(self, params, inherit=None):
+        """``inherit``: the group these parameters lived in before they were moved (``model.to()``, ``.float()``,
+        ``load_state_dict(assign=True)`` ... after the first step): its Adam moments and step count carry over, so
+        losing ownership never silently restarts the optimiser."""
         self.params = [p for p in params]
         assert self.params, "empty parameter group"
         dev = self.params[0].device
@@ -36,7 +39,67 @@ class FlatGroup:
                 self.flat_p[o:o + n].copy_(p.data.reshape(-1))
                 p.data = self.flat_p[o:o + n].view(p.shape)
         self._ws = torch.empty(lib.itcv_sumsq_workspace(total), dtype=torch.uint8, device=dev)
+        self._opt = None
         self.attach_grads()
+        if inherit is not None:
+            self._inherit(inherit)
+
+    def _inherit(self, old):
+        where = {id(p): (o, p.numel()) for p, o in zip(old.params, old.offsets)}
+        with torch.no_grad():
+            for p, o in zip(self.params, self.offsets):
+                src = where.get(id(p))
+                if src is not None and src[1] == p.numel():
+                    n = p.numel()
+                    self.exp_avg[o:o + n].copy_(old.exp_avg[src[0]:src[0] + n])
+                    self.exp_avg_sq[o:o + n].copy_(old.exp_avg_sq[src[0]:src[0] + n])
+            self.step_dev.copy_(old.step_dev)
+        self.step = old.step
+
+    # ---- torch.optim.Adam state mirror: optimizer.state_dict() / load_state_dict() keep working ----------------
+    def bind_optimizer(self, opt):
+        """Expose the moments as views inside ``opt.state`` (torch.optim.Adam's own keys) so ``opt.state_dict()``
+        saves them, and adopt whatever state ``opt`` already holds or later loads (``load_state_dict``).  The step
+        count lives on the device (graph replays advance it); it is copied into the state's ``step`` entries right
+        before a ``state_dict()`` call."""
+        if self._opt is opt:
+            return
+        self._opt = opt
+        self._adopt(opt)
+        if hasattr(opt, "register_state_dict_pre_hook"):
+            opt.register_state_dict_pre_hook(lambda o: self._refresh_steps(o))
+            opt.register_load_state_dict_post_hook(lambda o: self._adopt(o))
+
+    def _mine(self, t, buf, o, n):
+        return t is not None and t.data_ptr() == buf.data_ptr() + 4 * o and t.numel() == n and t.device == buf.device
+
+    def _adopt(self, opt):
+        step = None
+        with torch.no_grad():
+            for p, o in zip(self.params, self.offsets):
+                n = p.numel()
+                st = opt.state.get(p)
+                if st and "exp_avg" in st and not self._mine(st["exp_avg"], self.exp_avg, o, n):
+                    self.exp_avg[o:o + n].copy_(st["exp_avg"].reshape(-1))
+                    self.exp_avg_sq[o:o + n].copy_(st["exp_avg_sq"].reshape(-1))
+                    step = int(st["step"]) if step is None else max(step, int(st["step"]))
+                st = opt.state[p]
+                st["exp_avg"] = self.exp_avg[o:o + n].view(p.shape)
+                st["exp_avg_sq"] = self.exp_avg_sq[o:o + n].view(p.shape)
+                st.setdefault("step", torch.tensor(0.0))
+            if step is not None:
+                self.step = step
+                self.step_dev.fill_(step)
+        self._refresh_steps(opt)
+
+    def _refresh_steps(self, opt):
+        if opt is not self._opt:
+            return
+        step = float(int(self.step_dev.item()))
+        for p in self.params:
+            st = opt.state.get(p)
+            if st is not None:
+                st["step"] = torch.tensor(step)
 
     def owns(self, params):
         ps = list(params)

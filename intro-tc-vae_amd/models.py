@@ -106,8 +106,13 @@ def _conv(inc, outc, ks, bias=False):
     return HipConv2d(inc, outc, kernel_size=ks, stride=1, padding=ks // 2, groups=1, bias=bias)
 
 
-def _expand(inc, outc):
-    return _conv(inc, outc, 1) if inc != outc else None
+def _expand(inc, outc, by_identity=False):
+    """1x1 ``conv_expand`` of a block.  ``by_identity``: the reference's ConvolutionalBlock and InceptionResnetBlock
+    test ``inc is not outc`` (models.py:15,149) -- object identity, so two equal widths held by DIFFERENT int objects
+    (values > 256 parsed at run time, e.g. from a JSON config) still get the layer and its ``state_dict`` keys (and the
+    inception block then runs it on the skip path); ResidualBlock compares values (models.py:69).  Mirrored exactly."""
+    differs = (inc is not outc) if by_identity else (inc != outc)
+    return _conv(inc, outc, 1) if differs else None
 
 
 # ------------------------------------------------------------------------------ blocks
@@ -121,7 +126,7 @@ class ConvolutionalBlock(nn.Module):
             raise ValueError("groups != 1 is not supported by the HIP path")
         midc = int(outc * scale)
         self.eps = 1e-4
-        self.conv_expand = _expand(inc, outc)
+        self.conv_expand = _expand(inc, outc, by_identity=True)
         self.conv1 = _conv(inc, midc, 3)
         self.bn1 = HipBatchNorm2d(midc, eps=self.eps)
         self.relu1 = HipLeakyReLU(LRELU_SLOPE, inplace=True)
@@ -196,7 +201,7 @@ class InceptionResnetBlock(nn.Module):
         self.eps = 1e-4
         midc = int(outc * scale)
         assert outc % 2 == 0
-        self.conv_expand = _expand(inc, outc)
+        self.conv_expand = _expand(inc, outc, by_identity=True)
         self.branch_0 = Conv2dBatchNorm(inc, outc // 2, kernel_size=1, stride=1, groups=groups)
         self.branch_1 = nn.Sequential(
             Conv2dBatchNorm(inc, midc, kernel_size=1, stride=1, groups=groups),

@@ -83,7 +83,9 @@ class VAESolver:
         params = self._params(part)
         g = self._flat.get(part)
         if g is None or not g.owns(params):
-            g = self._flat[part] = FlatGroup(params)
+            # ownership lost (model.to() / .float() / load_state_dict(assign=True) after the first step): the new group
+            # inherits the Adam moments and step count instead of restarting them
+            g = self._flat[part] = FlatGroup(params, inherit=g)
         return g
 
     def _set_trainable(self, encoder: bool, decoder: bool):
@@ -122,7 +124,9 @@ class VAESolver:
         if hp is None:
             opt.step()                       # non-Adam optimiser supplied by the caller: torch's own update
         else:
-            self._group(part).adam_step(*hp)
+            g = self._group(part)
+            g.bind_optimizer(opt)            # moments visible in (and adopted from) opt.state / state_dict()
+            g.adam_step(*hp)
 
     # ---- step execution: eager, or one hipGraph replay -----------------------------------------
     def enable_graph(self, flag: bool = True):
@@ -133,6 +137,7 @@ class VAESolver:
         anything else silently runs eagerly."""
         self._graph_on = bool(flag)
         self._graph = None
+        self._graphs, self._graph_warm = {}, {}
         return self
 
     def _graph_ok(self):
@@ -150,24 +155,34 @@ class VAESolver:
     def _run_scoped(self, real: Tensor) -> Tensor:
         if not self._graph_ok():
             return self._device_step(real)
-        key = (tuple(real.shape), real.dtype, self.conv_math)
-        if getattr(self, "_graph", None) is None or self._graph_key != key:
-            self._graph_warm = getattr(self, "_graph_warm", 0) + 1
-            if self._graph_warm <= 3:
-                return self._device_step(real)          # eager warm-up: allocator, flat buffers, caches
-            from hipvae.functional import bump_weight_epoch
-            self._graph_in = real.clone()
+        # lr / betas / eps are scalar kernel arguments frozen into a captured graph: they are part of its key, so a
+        # scheduler or manual decay of param_groups[0]["lr"] re-captures instead of being silently ignored
+        key = (tuple(real.shape), real.dtype, self.conv_math, plain_adam_hparams(self.optimizer_e),
+               plain_adam_hparams(self.optimizer_d))
+        from hipvae.functional import bump_weight_epoch
+        graphs = self.__dict__.setdefault("_graphs", {})
+        ent = graphs.get(key)
+        if ent is None:
+            # eager warm-up before a capture: 3 steps for the first graph (allocator, flat buffers, caches), one for
+            # every further key (a new batch shape -- the last partial batch of an epoch -- or new hyper-parameters)
+            warm = self.__dict__.setdefault("_graph_warm", {})
+            warm[key] = warm.get(key, 0) + 1
+            if warm[key] <= (3 if not graphs else 1):
+                return self._device_step(real)
+            while len(graphs) >= 4:                       # keep a handful of shapes alive; the oldest goes first
+                graphs.pop(next(iter(graphs)))
+            ent = dict(inp=real.clone())
             bump_weight_epoch()                          # every weight gets re-packed inside the graph
             torch.cuda.synchronize()
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                self._graph_out = self._device_step(self._graph_in)
-            self._graph, self._graph_key = graph, key
-        from hipvae.functional import bump_weight_epoch
-        self._graph_in.copy_(real)
-        self._graph.replay()
+            ent["graph"] = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(ent["graph"]):
+                ent["out"] = self._device_step(ent["inp"])
+            graphs[key] = ent
+        self._graph, self._graph_key, self._graph_in, self._graph_out = ent["graph"], key, ent["inp"], ent["out"]
+        ent["inp"].copy_(real)
+        ent["graph"].replay()
         bump_weight_epoch()                              # eager users after a replay must re-pack
-        return self._graph_out
+        return ent["out"]
 
     # ---- solvers/vae.py:89-136 ---------------------------------------------------------------
     def _device_step(self, real: Tensor) -> Tensor:

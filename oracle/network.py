@@ -114,6 +114,8 @@ def run(steps, sd, x, train=True):
         elif op == "inception":
             _, prefix, expand = st
             inp = stack.pop()
+            # models.py:149 tests ``inc is not outc`` (identity): the layer may exist, and then runs, for equal widths
+            expand = (prefix + "conv_expand.weight") in sd
             skip = F.conv2d(inp, sd[prefix + "conv_expand.weight"]) if expand else inp
             b0 = _conv_bn_act(sd, prefix + "branch_0.", inp, train)
             b1 = _conv_bn_act(sd, prefix + "branch_1.0.", inp, train)

@@ -77,9 +77,8 @@ def latent_inputs(B, D, seed):
     return z, mu, logvar, eps
 
 
-def gen_ops():
-    out = {}
-    for tag, (B, D, N) in {"a": (16, 10, 1000), "b": (64, 128, 10000), "c": (256, 64, 10000)}.items():
+def latent_cases(cases, out):
+    for tag, (B, D, N) in cases.items():
         z, mu, logvar, eps = latent_inputs(B, D, seed=100 + B)
         out[f"{tag}_BDN"] = np.array([B, D, N], dtype=np.int64)
         out[f"{tag}_z"], out[f"{tag}_mu"], out[f"{tag}_logvar"] = npy(z), npy(mu), npy(logvar)
@@ -130,6 +129,19 @@ def gen_ops():
         out[f"{tag}_full_dwkl"] = npy(pm2 - logpz)
         # reparameterize with the recorded eps (ops.py:183-185)
         out[f"{tag}_reparam"] = npy(mu + eps * torch.exp(0.5 * logvar))
+
+
+def gen_ops_c4():
+    """BASELINE configs[3] (c4): global batch 512, z_dim 128, N = 10000 -- the size SURVEY.md section 8(c) names.
+    The reference materialises the [512,512,128] pairwise tensor (134 MB fp32) and its autograd copies: ~2 GB."""
+    out = {}
+    latent_cases({"d": (512, 128, 10000)}, out)
+    save("ops_c4.npz", **out)
+
+
+def gen_ops():
+    out = {}
+    latent_cases({"a": (16, 10, 1000), "b": (64, 128, 10000), "c": (256, 64, 10000)}, out)
     # reconstruction losses (ops.py:188-236) incl. the KATs of tests/test_ops.py:10-43
     g = torch.Generator().manual_seed(7)
     x = torch.rand(6, 3, 8, 8, generator=g)
@@ -313,6 +325,8 @@ if __name__ == "__main__":
     which = sys.argv[1:] or ["ops", "models", "steps"]
     if "ops" in which:
         gen_ops()
+    if "ops_c4" in which or not sys.argv[1:]:
+        gen_ops_c4()
     if "models" in which:
         gen_models()
     if "steps" in which:

@@ -127,3 +127,21 @@ def test_checkpoint_roundtrip(tmp_path, monkeypatch):
     utils.load_model(m2, path, "cpu")
     for (k, a), (_, b) in zip(m.state_dict().items(), m2.state_dict().items()):
         assert torch.equal(a, b), k
+
+
+def test_conv_expand_identity_quirk():
+    """models.py:15,149 create ``conv_expand`` when ``inc is not outc`` (identity, not value): equal widths above
+    CPython's small-int cache held by different objects (a JSON-parsed config) get the layer; the literal lists of
+    train.py:56-92 (one constant object per value) do not.  ResidualBlock (models.py:69) compares values."""
+    import json
+    import models
+    lit = models.SoftIntroVAE(arch="conv", cdim=3, zdim=4, channels=(8, 300, 300), image_size=16)
+    assert not any("conv_expand" in k and "res_in_4.c" in k for k in lit.state_dict())
+    parsed = json.loads("[8, 300, 300]")
+    assert parsed[1] is not parsed[2]
+    m = models.SoftIntroVAE(arch="conv", cdim=3, zdim=4, channels=parsed, image_size=16)
+    keys = [k for k in m.state_dict() if "conv_expand" in k]
+    assert "encoder.main.res_in_4.conv_expand.weight" in keys          # 300 -> 300 by two objects
+    assert "encoder.main.res_in_2.conv_expand.weight" not in keys      # conv_block(cc, cc): the same object
+    r = models.SoftIntroVAE(arch="res", cdim=3, zdim=4, channels=parsed, image_size=16)
+    assert "encoder.main.res_in_4.conv_expand.weight" not in r.state_dict()

@@ -27,7 +27,7 @@ def _free_port():
 
 
 def _setup(rank, world, port, backend="gloo"):
-    for p in (os.path.join(ROOT, "intro-tc-vae_amd"), ROOT):
+    for p in (os.path.join(ROOT, "intro-tc-vae_amd"), ROOT, os.path.join(ROOT, "tests")):
         if p not in sys.path:
             sys.path.insert(0, p)
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
@@ -216,3 +216,87 @@ def test_ddp_step_graph_capture_with_rccl():
     assert r["cap_g"] and not r["cap_e"]
     np.testing.assert_allclose(np.array(r["graph"], dtype=np.float64), np.array(r["eager"], dtype=np.float64), rtol=2e-4)
     assert r["pdiff"] < 1e-5
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# BASELINE configs[3] (c4) at a batch the CPU oracle finishes in seconds: the c2 network (64x64x3, z=128, channels
+# (64,128,256,512)), global batch 8 sharded over 2 processes with Sync-BN, against the oracle's single-process
+# full-batch step.
+C2 = dict(cdim=3, zdim=128, channels=(64, 128, 256, 512), image_size=64)
+C2_HP = dict(beta_kl=0.5, beta_rec=0.75, beta_neg=512.0, gamma_r=1e-8, clip=100.0, lr=2e-4, n=10000)
+
+
+def _c2_inputs(B=8):
+    g = torch.Generator().manual_seed(1234)
+    x = torch.rand(B, 3, 64, 64, generator=torch.Generator().manual_seed(0))
+    return x, [torch.randn(B, C2["zdim"], generator=g) for _ in range(6)]
+
+
+def _c2_worker(rank, world, port, out, math):
+    _setup(rank, world, port, "gloo")
+    import contextlib
+    import io
+    import models
+    from hipvae import ddp
+    from solvers.intro_tc import IntroTCSovler
+    from step_trace import traced_hip_step
+    ddp.init(sync_bn=True)
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    with contextlib.redirect_stdout(io.StringIO()):
+        model = models.SoftIntroVAE(arch="conv", **C2)
+    model = model.to(dev).train()
+
+    class DS:
+        def __len__(self):
+            return C2_HP["n"]
+
+    x, draws = _c2_inputs()
+    Bl = x.shape[0] // world
+    sl = slice(rank * Bl, (rank + 1) * Bl)
+    solver = IntroTCSovler(DS(), model, Bl, torch.optim.Adam(model.encoder.parameters(), lr=C2_HP["lr"]),
+                           torch.optim.Adam(model.decoder.parameters(), lr=C2_HP["lr"]), "mse", C2_HP["beta_kl"],
+                           C2_HP["beta_rec"], C2_HP["beta_neg"], C2_HP["gamma_r"], dev, False, None, clip=C2_HP["clip"])
+    solver.conv_math = math
+    tr = traced_hip_step(solver, model, x[sl], [t[sl].clone() for t in draws])
+    out[rank] = dict(dict=tr["dict"], decoded=[t.numpy() for t in tr["decoded"]],
+                     encoded=[[t.numpy() for t in pair] for pair in tr["encoded"]],
+                     kl=[t.numpy() for t in tr["kl"]], rec=[t.numpy() for t in tr["rec"]],
+                     grads=[{k: v.numpy() for k, v in g.items()} for g in tr["grads"]])
+    ddp.shutdown()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("math", ["fp32", "bf16x3"])
+def test_ddp_c2_shape_step_vs_oracle(math):
+    """Two processes x 4 images, Sync-BN, all-gathered means for the TC estimator, averaged gradients == the oracle's
+    single-process step on the 8 images: returned scalars, every image / encoder output of the local rows, the
+    per-sample hook outputs of the local rows, and the averaged gradients of both phases."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from oracle.network import Net
+    from oracle.steps import Trainer
+    from step_trace import STEP_TOL, rel_err, traced_oracle_step
+    import contextlib
+    import io
+    import models
+    torch.manual_seed(0)
+    with contextlib.redirect_stdout(io.StringIO()):
+        sd = {k: v.clone() for k, v in models.SoftIntroVAE(arch="conv", **C2).state_dict().items()}
+    x, draws = _c2_inputs()
+    tr = Trainer("intro_tc", Net("conv", state=sd, **C2), dataset_size=C2_HP["n"], beta_kl=C2_HP["beta_kl"],
+                 beta_rec=C2_HP["beta_rec"], beta_neg=C2_HP["beta_neg"], gamma_r=C2_HP["gamma_r"], clip=C2_HP["clip"],
+                 lr=C2_HP["lr"])
+    ref = traced_oracle_step(tr, x, draws)
+    world, port = 2, _free_port()
+    with mp.Manager() as m:
+        out = m.dict()
+        mp.spawn(_c2_worker, args=(world, port, out, math), nprocs=world, join=True)
+        res = dict(out)
+    assert res[0]["dict"] == res[1]["dict"]
+    for k in ("loss_enc", "loss_dec", "loss_kl", "loss_rec", "L2"):
+        t = 1e-3 if (k == "L2" and math == "bf16x3") else 1e-4
+        assert abs(res[0]["dict"][k] - ref["dict"][k]) <= t * abs(ref["dict"][k]), (k, res[0]["dict"][k], ref["dict"][k])
+    from step_trace import compare_traces
+    for r in (0, 1):
+        compare_traces(res[r], ref, STEP_TOL[math], f"ddp c2 {math} rank {r}", rows=slice(r * 4, (r + 1) * 4))

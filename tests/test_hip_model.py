@@ -176,13 +176,19 @@ def test_steps_bce_golden():
     run_golden_steps("steps_conv_bce.npz", "conv", "bce", ("vae", "intro_tc"), 1)
 
 
+from step_trace import STEP_TOL, compare_traces, traced_hip_step, traced_oracle_step, worst  # noqa: E402
+
+
 @pytest.mark.parametrize("math", MATH_MODES)
 def test_intro_tc_step_64x64_vs_oracle(math):
     """The benchmark shape at a batch the CPU oracle finishes in seconds (64x64x3, z=128,
     channels (64,128,256,512), B=8): one intro-TC step, HIP vs oracle on identical weights / draws,
     in every conv arithmetic (exact fp32 MFMA, bf16x6, bf16x3 = the benchmark's use_amp mode).
-    Bar: every returned scalar within 1e-4 relative."""
+    Bar: every returned scalar within 1e-4 relative; every reconstruction / sample image, encoder output,
+    KL / reconstruction hook output, per-tensor gradient of both phases and the (mi, tc, dwkl) decomposition
+    within STEP_TOL[math]."""
     import models
+    from oracle import latent_math as lm
     from oracle.network import Net
     from oracle.steps import Trainer
     cfg = dict(cdim=3, zdim=128, channels=(64, 128, 256, 512), image_size=64)
@@ -196,20 +202,27 @@ def test_intro_tc_step_64x64_vs_oracle(math):
     g = torch.Generator().manual_seed(1234)
     x = torch.rand(8, 3, 64, 64, generator=torch.Generator().manual_seed(0))
     draws = [torch.randn(8, 128, generator=g) for _ in range(6)]
-    import ops
-    with ops.noise_queue(draws):
-        d = solver.train_step(x, 0)
+    got = traced_hip_step(solver, model, x, [t.clone() for t in draws])
     tr = Trainer("intro_tc", Net("conv", state=sd, **cfg), dataset_size=10000, beta_kl=0.5, beta_rec=0.75,
                  beta_neg=512.0, gamma_r=1e-8, clip=100.0, lr=2e-4)
-    ref = tr.step(x, draws)
+    ref = traced_oracle_step(tr, x, draws)
+    d, r = got["dict"], ref["dict"]
     for k in ("loss_enc", "loss_dec", "loss_kl", "loss_rec", "L2"):
         # every loss / KL / reconstruction term within 1e-4 in every arithmetic.  L2 is the clipped
         # gradient-norm diagnostic: 2^-16-per-product rounding of the bf16x3 backward GEMMs shows there
         # first (measured 2.4e-4; fp32 and bf16x6 stay at 6e-5), so it is held to 1e-3 in that mode only.
         tol = 1e-3 if (k == "L2" and math == "bf16x3") else 1e-4
-        assert abs(d[k] - ref[k]) <= tol * abs(ref[k]), (k, d[k], ref[k])
-    dec = solver.kl_decomposition(*(t.to(dev()) for t in (draws[0], draws[1], draws[2])))
-    assert all(t.shape == (8,) for t in dec)
+        assert abs(d[k] - r[k]) <= tol * abs(r[k]), (k, d[k], r[k])
+    compare_traces(got, ref, STEP_TOL[math], math)
+    # decomposed KL terms (solvers/tc.py:104-121 as metrics) on the step's own posterior of the real batch
+    mu_h, lv_h = got["encoded"][0]
+    mu_o, lv_o = ref["encoded"][0]
+    z_h, z_o = mu_h + draws[1] * (0.5 * lv_h).exp(), mu_o + draws[1] * (0.5 * lv_o).exp()
+    dec_h = solver.kl_decomposition(*(t.to(dev()) for t in (z_h, mu_h, lv_h)))
+    dec_o = lm.decomposition(z_o, mu_o, lv_o, 10000)
+    e_dec = worst(zip(dec_h, dec_o))
+    print(f"[{math}] (mi, tc, dwkl) decomposition {e_dec:.2e}")
+    assert all(t.shape == (8,) for t in dec_h) and e_dec < STEP_TOL[math]["dec"]
 
 
 @pytest.mark.parametrize("math,size,zdim,channels,B", [
@@ -273,3 +286,98 @@ def test_graph_replay_equals_eager():
         for k in a:
             assert abs(a[k] - b[k]) <= 1e-5 * abs(a[k]) + 1e-9, (k, a[k], b[k])
     assert float((out["eager_w"] - out["graph_w"]).abs().max()) < 1e-6
+
+
+class StubWriter:
+    """Stands in for torch.utils.tensorboard.SummaryWriter: records every call the solvers make."""
+
+    def __init__(self):
+        self.calls = []
+
+    def add_images(self, tag, img_tensor, global_step=None):
+        assert img_tensor.device.type == "cpu"          # the reference hands over ``.data.cpu()`` (vae.py:151-160)
+        self.calls.append(("add_images", tag, img_tensor.clone(), global_step))
+
+    def add_scalar(self, tag, value, global_step=None):
+        self.calls.append(("add_scalar", tag, float(value), global_step))
+
+    def add_scalars(self, tag, values, global_step=None):
+        self.calls.append(("add_scalars", tag, {k: float(v) for k, v in values.items()}, global_step))
+
+    def flush(self):
+        self.calls.append(("flush",))
+
+    def of(self, kind, tag):
+        return [c for c in self.calls if c[0] == kind and c[1] == tag]
+
+
+@pytest.mark.parametrize("name", ["intro_tc", "vae"])
+def test_image_logging_grid_vs_oracle(name):
+    """with a writer set and cur_iter % test_iter == 0 the step logs the [real | deterministic
+    reconstruction | fake] grid (solvers/vae.py:138-163, intro.py:187-191): the deterministic reconstruction is
+    ``model(batch, deterministic=True)`` on the UPDATED weights with BatchNorm still in train mode (batch statistics,
+    running buffers advanced once more); ``fake`` is phase D's sample for the intro solvers and a fresh N(0,1)
+    sample for the VAE solvers.  Checked against the oracle, with the scalars the reference logs beside it."""
+    import ops
+    from oracle.network import Net
+    from oracle.steps import Trainer
+    from utils import SingletonWriter
+    g = np.load(os.path.join(GOLDEN, "steps_conv.npz"))
+    hp = g["hp"]
+    state = load_state(g, "init:")
+    model = build("conv", state)
+    solver = make_solver(name, model, hp)
+    w = StubWriter()
+    solver.writer, solver.test_iter = w, 5
+    SingletonWriter().writer, SingletonWriter().cur_iter, SingletonWriter().test_iter = w, 10, 5
+    try:
+        x = T(g["x0"])
+        p = f"{name}:s0:"
+        nd = len([k for k in g.files if k.startswith(p + "draw")])
+        draws = [T(g[p + f"draw{i}"]) for i in range(nd)]
+        torch.cuda.manual_seed(77)
+        with ops.noise_queue([t.clone() for t in draws]):
+            d = solver.train_step(x, 10)
+    finally:
+        SingletonWriter().writer = None
+    np.testing.assert_allclose([d["loss_enc"], d["loss_dec"], d["loss_kl"], d["loss_rec"], d["L2"]], g[p + "dict"], rtol=1e-4)
+    tr = Trainer(name, Net("conv", state={k: v.clone() for k, v in state.items()}, **TINY), dataset_size=int(hp[6]),
+                 beta_kl=hp[0], beta_rec=hp[1], beta_neg=hp[2], gamma_r=hp[3], clip=hp[4], lr=hp[5])
+    ref = tr.step(x, draws)
+    if name == "vae":
+        torch.cuda.manual_seed(77)
+        noise = torch.randn(size=(x.size(0), TINY["zdim"]), device=dev()).cpu()    # the helper's draw (vae.py:141-143)
+        with torch.no_grad():
+            fake_ref = tr.net.decode(noise)
+    else:
+        fake_ref = tr.trace["last_fake"]
+    with torch.no_grad():
+        rec_det = tr.net.decode(tr.net.encode(x)[0])
+    grid_ref = torch.cat([x, rec_det, fake_ref], dim=0)
+    (call,) = w.of("add_images", "reconstructions")
+    assert call[3] == 10 and call[2].shape == grid_ref.shape == (3 * x.size(0), 3, 32, 32)
+    assert rel_err(call[2], grid_ref) < 1e-4
+    # BatchNorm buffers after the logging pass (one more train-mode forward of both halves) equal the oracle's
+    sd = model.state_dict()
+    for k, v in tr.net.sd.items():
+        if "running" in k:
+            assert rel_err(sd[k], v) < 1e-3, k
+        if "num_batches" in k:
+            assert int(sd[k]) == int(v), k
+    # scalars beside the grid
+    (losses,) = w.of("add_scalars", "losses")
+    assert abs(losses[2]["r_loss"] - ref["loss_rec"]) <= 1e-4 * abs(ref["loss_rec"])
+    assert abs(losses[2]["kl_loss"] - ref["loss_kl"]) <= 1e-4 * abs(ref["loss_kl"])
+    assert w.of("add_scalar", "fc_grad_norm") and w.calls[-1] == ("flush",)
+    if name == "intro_tc":
+        (norms,) = w.of("add_scalars", "total_norm")
+        np.testing.assert_allclose([norms[2]["E"], norms[2]["D"]], tr.trace["norms"], rtol=1e-4)
+        assert abs(w.of("add_scalar", "lossE")[0][2] - ref["loss_enc"]) <= 1e-4 * abs(ref["loss_enc"])
+        assert abs(w.of("add_scalar", "lossD")[0][2] - ref["loss_dec"]) <= 1e-4 * abs(ref["loss_dec"])
+        assert abs(losses[2]["expelbo_f"] - tr.trace["expelbo"][1]) <= 1e-4 * abs(tr.trace["expelbo"][1])
+        assert w.of("add_scalar", "diff_kl")
+    # off-iteration: nothing but scalars
+    w.calls.clear()
+    with ops.noise_queue([t.clone() for t in draws]):
+        solver.train_step(x, 11)
+    assert not w.of("add_images", "reconstructions")

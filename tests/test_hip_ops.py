@@ -232,12 +232,13 @@ def test_pointwise_and_resampling(HF):
     assert rel_err(HF.AddFn.apply(a.to(dev()), b.to(dev())), a + b) == 0
 
 
-@pytest.mark.parametrize("tag", ["a", "b", "c"])
+@pytest.mark.parametrize("tag", ["a", "b", "c", "d"])
 def test_latent_against_golden(HF, tag):
-    """Reference-generated vectors (tests/golden/ops.npz): KL, reparameterise, MSS/MWS, TC, the full
-    decomposition and the gradients of (beta-1)TC + KL, with both clamps of ops.py:18,21 firing."""
+    """Reference-generated vectors (tests/golden/ops.npz; tag d = ops_c4.npz, the c4 size B=512, D=128, N=10000):
+    KL, reparameterise, MSS/MWS, TC, the full decomposition and the gradients of (beta-1)TC + KL, with both clamps
+    of ops.py:18,21 firing."""
     import ops
-    G = np.load(os.path.join(GOLDEN, "ops.npz"))
+    G = np.load(os.path.join(GOLDEN, "ops_c4.npz" if tag == "d" else "ops.npz"))
     B, D, N = (int(v) for v in G[f"{tag}_BDN"])
     d = dev()
     z, mu, lv, eps = (torch.from_numpy(G[f"{tag}_{k}"]).to(d) for k in ("z", "mu", "logvar", "eps"))
@@ -267,6 +268,51 @@ def test_latent_against_golden(HF, tag):
     assert rel_err(zz.grad, T("tcw_dz")) < 1e-4
     assert rel_err(mm.grad, T("tcw_dmu")) < 1e-4
     assert rel_err(ll.grad, T("tcw_dlogvar")) < 1e-4
+
+
+def test_tc_c4_eight_shards_against_golden(HF):
+    """BASELINE configs[3] (c4): global batch 512 as 8 data-parallel shards of 64 rows.  Every shard evaluates its
+    rows with the all-gathered means (``mu_all``) and its global ``row_offset`` -- what each rank of the 8-GPU run
+    computes (ops.py:52-115 on the full batch) -- forward and backward against the values the unmodified reference
+    produced on the whole [512,128] batch (tests/golden/ops_c4.npz): per-row TC, the (beta-1)TC+KL loss at beta=512
+    and 0.5 with d/dz, d/dmu (sum of the shards' contributions = the reduce-scatter) and d/dlogvar, and the
+    per-row-weighted form.  Tolerance 1e-4 relative (north_star)."""
+    import ops
+    G = np.load(os.path.join(GOLDEN, "ops_c4.npz"))
+    B, D, N = (int(v) for v in G["d_BDN"])
+    assert (B, D, N) == (512, 128, 10000)
+    R, Bl = 8, 64
+    d = dev()
+    z, mu, lv = (torch.from_numpy(G[f"d_{k}"]).to(d) for k in ("z", "mu", "logvar"))
+    T = lambda k: torch.from_numpy(G[f"d_{k}"])  # noqa: E731
+
+    def sharded_tc(zz, mm, ll):
+        return torch.cat([ops.total_correlation(zz[r * Bl:(r + 1) * Bl], mm[r * Bl:(r + 1) * Bl], ll[r * Bl:(r + 1) * Bl],
+                                                N, "none", mu_all=mm, row_offset=r * Bl) for r in range(R)])
+
+    assert rel_err(sharded_tc(z, mu, lv), T("tc_none")) < 1e-4
+    assert rel_err(sharded_tc(z, mu, lv).mean(), T("tc_mean")) < 1e-4
+    for beta, bt in ((512.0, "512p0"), (0.5, "0p5")):
+        zz, mm, ll = (t.clone().requires_grad_(True) for t in (z, mu, lv))
+        loss = (beta - 1.0) * sharded_tc(zz, mm, ll).mean() + ops.kl_divergence(ll, mm, "mean")
+        loss.backward()
+        assert rel_err(loss, T(f"tckl_b{bt}")) < 1e-4
+        assert rel_err(zz.grad, T(f"tckl_b{bt}_dz")) < 1e-4
+        assert rel_err(mm.grad, T(f"tckl_b{bt}_dmu")) < 1e-4
+        assert rel_err(ll.grad, T(f"tckl_b{bt}_dlogvar")) < 1e-4
+    zz, mm, ll = (t.clone().requires_grad_(True) for t in (z, mu, lv))
+    (T("tcw_w").to(d) * sharded_tc(zz, mm, ll)).sum().backward()
+    assert rel_err(zz.grad, T("tcw_dz")) < 1e-4
+    assert rel_err(mm.grad, T("tcw_dmu")) < 1e-4
+    assert rel_err(ll.grad, T("tcw_dlogvar")) < 1e-4
+    # the sampler components a rank reports: stratified and weighted, per shard
+    for weighted, key in ((False, "mss"), (True, "mws")):
+        flags = HF.abi.TC_VAR_FROM_ROW | HF.abi.TC_EPS_DENSITY | (HF.abi.TC_WEIGHTED if weighted else 0)
+        pm, lq = [], []
+        for r in range(R):
+            a, b, _ = HF.tc_components(z[r * Bl:(r + 1) * Bl], mu, lv[r * Bl:(r + 1) * Bl], N, r * Bl, flags)
+            pm.append(a), lq.append(b)
+        assert rel_err(torch.cat(pm), T(f"{key}_prodm")) < 1e-4 and rel_err(torch.cat(lq), T(f"{key}_logqz")) < 1e-4
 
 
 def test_tc_sharded_rows_equal_full_batch(HF):

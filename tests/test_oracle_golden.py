@@ -25,10 +25,15 @@ def close(a, b, rtol=1e-5, atol=1e-6):
 
 @pytest.fixture(scope="module")
 def G():
-    return np.load(os.path.join(GOLDEN, "ops.npz"))
+    """ops.npz (tags a, b, c + reconstruction) and ops_c4.npz (tag d: the c4 size, B_glob=512, D=128, N=10000)."""
+    both = {}
+    for f in ("ops.npz", "ops_c4.npz"):
+        z = np.load(os.path.join(GOLDEN, f))
+        both.update({k: z[k] for k in z.files})
+    return both
 
 
-@pytest.mark.parametrize("tag", ["a", "b", "c"])
+@pytest.mark.parametrize("tag", ["a", "b", "c", "d"])
 def test_latent_forward(G, tag):
     B, D, N = (int(v) for v in G[f"{tag}_BDN"])
     z, mu, lv, eps = (T(G[f"{tag}_{k}"]) for k in ("z", "mu", "logvar", "eps"))
@@ -52,7 +57,7 @@ def test_latent_forward(G, tag):
     close(dw, G[f"{tag}_full_dwkl"], rtol=1e-4, atol=1e-3)
 
 
-@pytest.mark.parametrize("tag", ["a", "b", "c"])
+@pytest.mark.parametrize("tag", ["a", "b", "c", "d"])
 def test_latent_gradients(G, tag):
     B, D, N = (int(v) for v in G[f"{tag}_BDN"])
     for beta, bt in ((512.0, "512p0"), (0.5, "0p5")):
@@ -75,7 +80,7 @@ def test_latent_gradients(G, tag):
 
 def test_clamps_fire(G):
     """The fixtures exercise both clamps of ops.py:18,21."""
-    for tag in "abc":
+    for tag in "abcd":
         assert G[f"{tag}_frac_clamp50"][0] > 0.1
         assert G[f"{tag}_frac_varclamp"][0] > 0.0
 
