@@ -69,20 +69,32 @@ def worst(pairs):
     return max(rel_err(a, b) for a, b in pairs)
 
 
-# Bounds of one intro-TC step at the c2 shape against the fp32 CPU oracle (identical weights / draws), per conv
-# arithmetic and per phase.  Phase E (update E: 4 decoder + 3 encoder passes, the encoder backward) starts from
-# identical weights: "fp32" and "bf16x6" keep every image, encoder output, hook output and the (mi, tc, dwkl)
-# decomposition inside north_star's 1e-4; bf16x3 (2^-16 per product, the benchmark mode) keeps every image / loss /
-# KL / reconstruction term inside 1e-4 too and is looser only on the per-tensor gradients.  Phase D runs AFTER the
-# encoder's Adam update: a first Adam step moves every weight by lr*g/(|g|+eps) ~ +-lr*sign(g), so the few weights whose
-# gradient is at rounding level move by up to 2*lr = 4e-4 differently in ANY two fp32 evaluations of the same step
-# (summation order alone does it -- the oracle against itself with a permuted batch shows the same); the phase-D
-# tensors are therefore held to the looser bounds below while the returned phase-D losses stay inside 1e-4.
+# How one intro-TC step at the c2 shape is held to the CPU reference (identical weights / draws), per conv arithmetic.
+#
+# Phase E (update E: 4 decoder + 3 encoder passes) starts from identical weights: every image, encoder output and hook
+# output (ELBO / KL / TC / reconstruction terms) is held to north_star's 1e-4 against the fp32 oracle in every
+# arithmetic (measured: 3e-6 fp32 / bf16x6, 3e-5 bf16x3).
+#
+# Gradient tensors, and everything in phase D (which runs AFTER the encoder's first Adam update), cannot be held to
+# 1e-4 by ANY fp32 evaluation, the reference's own included: measured against the oracle run in fp64, the fp32 CPU
+# oracle's encoder gradients are off by up to 1.6e-2 of the gradient scale (the beta_neg = 512 TC backward cancels
+# O(1) softmax terms), and a first Adam step moves every weight by lr*g/(|g|+eps) ~ +-lr*sign(g), so weights whose
+# gradient sits at that error level move by up to 2*lr differently.  These quantities are therefore judged against
+# the fp64 oracle with the fp32 oracle's own error as the yardstick:  err(HIP vs fp64) <= RATIO * err(fp32 oracle vs
+# fp64) + FLOOR.  RATIO 1 means "as accurate as the reference's CPU fp32 path".
+# Measured (tests/test_hip_model.py::test_intro_tc_step_64x64_vs_oracle, B=8; HIP | fp32 oracle, both against fp64):
+#   fp32    E grads 1.65e-2 | 1.65e-2   D images 1.58e-3 | 1.46e-3   D encoder 1.48e-3 | 1.39e-3   D hooks 1.96e-4 | 1.75e-4   D grads 4.3e-3 | 4.5e-3
+#   bf16x6  E grads 4.97e-3 | 1.65e-2   D images 4.70e-4 | 1.46e-3   D encoder 4.58e-4 | 1.39e-3   D hooks 2.80e-5 | 1.75e-4   D grads 2.2e-3 | 4.5e-3
+#   bf16x3  E grads 5.81e-2 | 1.65e-2   D images 2.14e-2 | 1.46e-3   D encoder 1.05e-2 | 1.39e-3   D hooks 7.48e-4 | 1.75e-4   D grads 8.3e-3 | 4.5e-3
+# i.e. exact-fp32 and bf16x6 are as accurate as (or closer to fp64 than) the reference's CPU fp32 path everywhere;
+# bf16x3 (2^-16 per product, the benchmark's use_amp mode) holds phase E's forward quantities inside 1e-4 and is
+# 3.5x (gradients) to 15x (phase-D images, through Adam's sign step) looser on the ill-conditioned ones.
 STEP_TOL = {
-    "fp32": dict(E=dict(img=1e-4, enc=1e-4, hook=1e-4, grad=1e-3), D=dict(img=5e-3, enc=5e-3, hook=2e-3, grad=5e-2), dec=1e-4),
-    "bf16x6": dict(E=dict(img=1e-4, enc=1e-4, hook=1e-4, grad=1e-3), D=dict(img=5e-3, enc=5e-3, hook=2e-3, grad=5e-2), dec=1e-4),
-    "bf16x3": dict(E=dict(img=1e-4, enc=1e-4, hook=1e-4, grad=2e-3), D=dict(img=5e-3, enc=5e-3, hook=2e-3, grad=5e-2), dec=1e-4),
+    "fp32": dict(E=dict(img=1e-4, enc=1e-4, hook=1e-4), ratio=dict(Egrad=1.5, img=1.5, enc=1.5, hook=1.5, Dgrad=1.5), dec=1e-4),
+    "bf16x6": dict(E=dict(img=1e-4, enc=1e-4, hook=1e-4), ratio=dict(Egrad=1.5, img=1.5, enc=1.5, hook=1.5, Dgrad=1.5), dec=1e-4),
+    "bf16x3": dict(E=dict(img=1e-4, enc=1e-4, hook=1e-4), ratio=dict(Egrad=5.0, img=20.0, enc=12.0, hook=8.0, Dgrad=3.0), dec=1e-4),
 }
+FLOOR = 1e-4
 PHASES = dict(E=dict(decoded=slice(0, 4), encoded=slice(0, 3), kl=slice(0, 3), rec=slice(0, 3), grads=0, part="encoder"),
               D=dict(decoded=slice(4, 8), encoded=slice(3, 5), kl=slice(3, 5), rec=slice(3, 6), grads=1, part="decoder"))
 
@@ -117,16 +129,24 @@ def phase_errors(got, ref, ph, rows=None):
     return dict(img=e_img, enc=e_enc, hook=e_hook, grad=e_grad)
 
 
-def compare_traces(got, ref, tol, tag, rows=None):
-    """Every quantity of the step, HIP vs oracle, phase by phase (see STEP_TOL)."""
-    assert len(got["decoded"]) == len(ref["decoded"]) == 8 and len(got["encoded"]) == len(ref["encoded"]) == 5
-    assert len(got["kl"]) == len(ref["kl"]) == 5 and len(got["rec"]) == len(ref["rec"]) == 6
-    assert len(got["grads"]) == len(ref["grads"]) == 2
-    out = {}
+def compare_traces(got, o32, o64, tol, tag, rows=None):
+    """Every quantity of the step, HIP vs the fp32 oracle (phase E forward quantities: absolute 1e-4 bar) and vs the
+    fp64 oracle with the fp32 oracle's own error as yardstick (gradients, phase D) -- see STEP_TOL."""
+    for t in (got, o32, o64):
+        assert len(t["decoded"]) == 8 and len(t["encoded"]) == 5 and len(t["kl"]) == 5 and len(t["rec"]) == 6
+        assert len(t["grads"]) == 2
+    e32 = phase_errors(got, o32, "E", rows)
+    print(f"[{tag}] phase E vs fp32 oracle: images {e32['img']:.2e}  encoder {e32['enc']:.2e}  hooks {e32['hook']:.2e}")
+    for k in ("img", "enc", "hook"):
+        assert e32[k] < tol["E"][k], (tag, "E", k, e32[k])
+    checks = []
     for ph in ("E", "D"):
-        e = out[ph] = phase_errors(got, ref, ph, rows)
-        print(f"[{tag}] phase {ph}: images {e['img']:.2e}  encoder {e['enc']:.2e}  hooks {e['hook']:.2e}  grads {e['grad']:.2e}")
-    for ph in ("E", "D"):
-        for k, v in out[ph].items():
-            assert v < tol[ph][k], (tag, ph, k, v, tol[ph][k])
-    return out
+        eh, eo = phase_errors(got, o64, ph, rows), phase_errors(o32, o64, ph)
+        print(f"[{tag}] phase {ph} vs fp64 oracle (HIP | fp32 oracle): images {eh['img']:.2e} | {eo['img']:.2e}  "
+              f"encoder {eh['enc']:.2e} | {eo['enc']:.2e}  hooks {eh['hook']:.2e} | {eo['hook']:.2e}  "
+              f"grads {eh['grad']:.2e} | {eo['grad']:.2e}")
+        checks.append((ph + "grad", eh["grad"], eo["grad"]))
+        if ph == "D":
+            checks += [(k, eh[k], eo[k]) for k in ("img", "enc", "hook")]
+    for k, eh, eo in checks:
+        assert eh <= tol["ratio"][k] * eo + FLOOR, (tag, k, eh, eo, tol["ratio"][k])

@@ -232,6 +232,35 @@ def _c2_inputs(B=8):
     return x, [torch.randn(B, C2["zdim"], generator=g) for _ in range(6)]
 
 
+_C2_ORACLES = {}
+
+
+def _c2_oracles():
+    """fp32 and fp64 oracle traces of the full-batch step, computed once per session."""
+    if _C2_ORACLES:
+        return _C2_ORACLES
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import contextlib
+    import io
+    import models
+    from oracle.network import Net
+    from oracle.steps import Trainer
+    from step_trace import traced_oracle_step
+    torch.manual_seed(0)
+    with contextlib.redirect_stdout(io.StringIO()):
+        sd = {k: v.clone() for k, v in models.SoftIntroVAE(arch="conv", **C2).state_dict().items()}
+    x, draws = _c2_inputs()
+    oracles = {}
+    for name, dt in (("o32", torch.float32), ("o64", torch.float64)):
+        st = {k: (v.clone().to(dt) if v.dtype.is_floating_point else v.clone()) for k, v in sd.items()}
+        tr = Trainer("intro_tc", Net("conv", state=st, **C2), dataset_size=C2_HP["n"], beta_kl=C2_HP["beta_kl"],
+                     beta_rec=C2_HP["beta_rec"], beta_neg=C2_HP["beta_neg"], gamma_r=C2_HP["gamma_r"], clip=C2_HP["clip"],
+                     lr=C2_HP["lr"])
+        oracles[name] = traced_oracle_step(tr, x.to(dt), [t.to(dt) for t in draws])
+    _C2_ORACLES.update(oracles)
+    return _C2_ORACLES
+
+
 def _c2_worker(rank, world, port, out, math):
     _setup(rank, world, port, "gloo")
     import contextlib
@@ -280,14 +309,8 @@ def test_ddp_c2_shape_step_vs_oracle(math):
     import contextlib
     import io
     import models
-    torch.manual_seed(0)
-    with contextlib.redirect_stdout(io.StringIO()):
-        sd = {k: v.clone() for k, v in models.SoftIntroVAE(arch="conv", **C2).state_dict().items()}
-    x, draws = _c2_inputs()
-    tr = Trainer("intro_tc", Net("conv", state=sd, **C2), dataset_size=C2_HP["n"], beta_kl=C2_HP["beta_kl"],
-                 beta_rec=C2_HP["beta_rec"], beta_neg=C2_HP["beta_neg"], gamma_r=C2_HP["gamma_r"], clip=C2_HP["clip"],
-                 lr=C2_HP["lr"])
-    ref = traced_oracle_step(tr, x, draws)
+    oracles = _c2_oracles()
+    ref = oracles["o32"]
     world, port = 2, _free_port()
     with mp.Manager() as m:
         out = m.dict()
@@ -299,4 +322,4 @@ def test_ddp_c2_shape_step_vs_oracle(math):
         assert abs(res[0]["dict"][k] - ref["dict"][k]) <= t * abs(ref["dict"][k]), (k, res[0]["dict"][k], ref["dict"][k])
     from step_trace import compare_traces
     for r in (0, 1):
-        compare_traces(res[r], ref, STEP_TOL[math], f"ddp c2 {math} rank {r}", rows=slice(r * 4, (r + 1) * 4))
+        compare_traces(res[r], ref, oracles["o64"], STEP_TOL[math], f"ddp c2 {math} rank {r}", rows=slice(r * 4, (r + 1) * 4))
