@@ -192,7 +192,7 @@ def roofline_of(records, math, steps, eager_elapsed, where):
     }
 
 
-def measure(wl, math, dev, args, rank, world, sync, use_graph, ddp_on):
+def measure(wl, math, dev, args, rank, world, sync, use_graph, ddp_on, with_h2d=False):
     """Warm-up, roofline leg (K eager steps with per-launch events), timed leg.  Returns a dict of raw results."""
     from hipvae import functional as HF
     solver = make_solver(wl, math, dev)
@@ -243,9 +243,38 @@ def measure(wl, math, dev, args, rank, world, sync, use_graph, ddp_on):
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t)
+    h2d = None
+    if world == 1 and with_h2d:
+        # ---- the same K steps with every batch starting in pageable HOST memory (what a DataLoader hands over):
+        # hipvae.loader.PrefetchLoader stages it in pinned memory and copies it on a side stream while the previous
+        # step runs.  Reported beside `value`, never as `value` (which has its inputs resident in HBM).
+        from hipvae.loader import PrefetchLoader
+        host = [b.cpu() for b in batches]
+
+        class _Feed:
+            def __len__(self):
+                return args.steps
+
+            def __iter__(self):
+                return (host[i % len(host)] for i in range(args.steps))
+
+        loader = PrefetchLoader(_Feed(), None, device=dev)
+        for _ in range(2):                       # first pass allocates the pinned / device rings
+            sync()
+            t0 = time.perf_counter()
+            for i, xb in enumerate(loader):
+                last = solver.train_step(xb, args.warmup + 2 * args.steps + i)
+            sync()
+            t_h2d = time.perf_counter() - t0
+        h2d = {"value": round(B * args.steps / t_h2d, 2), "unit": "images/s", "ms_per_step": round(t_h2d / args.steps * 1e3, 3),
+               "bytes_per_step": int(batches[0].numel() * 4),
+               "note": "batches start in pageable host memory; hipvae.loader.PrefetchLoader (pinned ring, H2D on a side "
+                       "stream under the previous step); same execution mode as `value`"}
+        if rank == 0:
+            log(f"[{math}] host-fed: {args.steps} steps in {t_h2d:.3f} s")
     where = (", immediately before the timed hipGraph-replay steps" if use_graph else
              ", immediately before the timed eager steps" if ddp_on else " (the timed region)")
-    return dict(solver=solver, batches=batches, elapsed=elapsed, eager_elapsed=eager_elapsed, last=last,
+    return dict(solver=solver, batches=batches, elapsed=elapsed, eager_elapsed=eager_elapsed, last=last, h2d=h2d,
                 roofline=roofline_of(records, math, args.steps, eager_elapsed, where))
 
 
@@ -312,7 +341,7 @@ def main():
     ddp_on = ddp.get() is not None
     use_graph = not args.no_graph and (not ddp_on or ddp.graph_capturable())
     B = wl["batch"]
-    m = measure(wl, args.math, dev, args, rank, world, sync, use_graph, ddp_on)
+    m = measure(wl, args.math, dev, args, rank, world, sync, use_graph, ddp_on, with_h2d=not ddp_on)
     solver, batches, elapsed, eager_elapsed, last = m["solver"], m["batches"], m["elapsed"], m["eager_elapsed"], m["last"]
 
     images = B * world * args.steps
@@ -335,6 +364,8 @@ def main():
         "last_step": last,
         "roofline": m["roofline"],
     }
+    if m["h2d"] is not None:
+        out["host_fed"] = m["h2d"]
     # ---- N>1 over RCCL: the same K steps once more with the data-parallel step captured into the step hipGraph ----
     # The eager measurement above is complete and stays the fallback: a watchdog prints it -- with
     # "graph_leg": {"status": "abandoned", "reason": ...} -- and ends the process if the captured leg raises or makes no

@@ -175,7 +175,9 @@ class VAESolver:
             bump_weight_epoch()                          # every weight gets re-packed inside the graph
             torch.cuda.synchronize()
             ent["graph"] = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(ent["graph"]):
+            # thread-local capture mode: the input pipeline's staging thread (hipvae.loader) may allocate pinned memory or
+            # issue copies on its own stream while this thread captures
+            with torch.cuda.graph(ent["graph"], capture_error_mode="thread_local"):
                 ent["out"] = self._device_step(ent["inp"])
             graphs[key] = ent
         self._graph, self._graph_key, self._graph_in, self._graph_out = ent["graph"], key, ent["inp"], ent["out"]
