@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define ITCV_ABI_VERSION 1
+#define ITCV_ABI_VERSION 2
 
 /* ---- library ------------------------------------------------------------------------- */
 int itcv_abi_version(void);
@@ -172,8 +172,14 @@ int itcv_bn_eval_stats(const float* running_mean, const float* running_var, floa
  * added before the activation (ResidualBlock, models.py:113-114). */
 int itcv_bn_act_fwd(const float* x, const float* mean, const float* rstd, const float* gamma,
                     const float* beta, const float* skip, float* y, int B, int C, int H, int W,
-                    float slope, int pool, void* planes, int ns, void* stream);
-/* `planes` (may be NULL): the same launch also writes the output as pre-split bf16 planes
+                    float slope, int pool, void* planes, int ns, size_t plane_stride, void* stream);
+/* `plane_stride` (16-byte chunks; also in itcv_bn_act_bwd_apply / itcv_bn_train_fwd / itcv_bn_train_bwd): distance
+ * between consecutive planes of `planes` / `dx_planes`.  0 = B*(C/8)*Ho*Wo, i.e. the call covers the whole tensor.
+ * Non-zero: x / y / planes point at ONE BatchNorm GROUP of a larger batched tensor -- the solvers push several
+ * independent network passes (each a BatchNorm batch of its own, models.py:37) through the conv GEMMs as one batch,
+ * and normalise every group with its own call: statistics, running-buffer updates and their order stay those of
+ * separate passes.
+ * `planes` (may be NULL): the same launch also writes the output as pre-split bf16 planes
  * [ns][B][C/8][Ho][Wo] for the consumer conv (itcv_conv2d_fwd_bf16p / _wgrad_bf16p); needs
  * itcv_bn_act_planes_supported(C, H, W, pool).  The fp32 output is bitwise unchanged; with planes given,
  * `y` may be NULL (fp32 output not written: the consumer GEMMs read only the planes).  The same holds
@@ -195,7 +201,7 @@ int itcv_bn_act_bwd_apply(const float* x, const float* dy, const float* mean, co
                           const float* gamma, const float* beta, const float* skip, const double* dsums,
                           const double* local_dsums, double count, float* dx, float* dskip,
                           float* dgamma, float* dbeta, int accumulate, int B, int C, int H, int W,
-                          float slope, int pool, int up2, void* dx_planes, int ns, void* stream);
+                          float slope, int pool, int up2, void* dx_planes, int ns, size_t plane_stride, void* stream);
 
 /* Single-rank training forms: itcv_bn_train_fwd == itcv_bn_train_stats + itcv_bn_act_fwd and
  * itcv_bn_train_bwd == itcv_bn_act_bwd_reduce + itcv_bn_act_bwd_apply (count = B*H*W), same arguments and results;
@@ -204,11 +210,11 @@ int itcv_bn_act_bwd_apply(const float* x, const float* dy, const float* mean, co
 int itcv_bn_train_fwd(const float* x, const float* gamma, const float* beta, const float* skip, float* y, void* planes,
                       int ns, int B, int C, int H, int W, float slope, int pool, float eps, float momentum,
                       float* running_mean, float* running_var, int64_t* num_batches_tracked, float* mean, float* rstd,
-                      void* ws, size_t ws_bytes, void* stream);
+                      void* ws, size_t ws_bytes, size_t plane_stride, void* stream);
 int itcv_bn_train_bwd(const float* x, const float* dy, const float* mean, const float* rstd, const float* gamma,
                       const float* beta, const float* skip, double* dsums, float* dx, float* dskip, void* dx_planes,
                       int ns, float* dgamma, float* dbeta, int accumulate, int B, int C, int H, int W, float slope,
-                      int pool, int up2, void* ws, size_t ws_bytes, void* stream);
+                      int pool, int up2, void* ws, size_t ws_bytes, size_t plane_stride, void* stream);
 
 /* ---- pointwise / resampling ----------------------------------------------------------- */
 int itcv_lrelu_fwd(const float* x, float* y, size_t n, float slope, void* stream);     /* models.py:271 */

@@ -211,13 +211,13 @@ template <int POOL, int NS, bool STATS>
 __global__ __launch_bounds__(256) void bn_act_fwd_planes_kernel(
     const float* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ rstd,
     const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ skip,
-    float* __restrict__ y, u32x4* __restrict__ planes, int B, int C, int H, int W, float slope, BnStatsIn st) {
+    float* __restrict__ y, u32x4* __restrict__ planes, int B, int C, int H, int W, float slope, BnStatsIn st,
+    size_t plane_stride) {
   __shared__ float s_mean[STATS ? kStatCh : 1], s_rstd[STATS ? kStatCh : 1];
   const int HW = H * W, C8 = C >> 3;
   const int Ho = POOL ? H / 2 : H, Wo = POOL ? W / 2 : W, HWo = Ho * Wo;
   constexpr int PX = POOL ? 2 : 4;                      // output pixels per thread
   const uint32_t per_plane = (uint32_t)HWo / PX, total = (uint32_t)B * C8 * per_plane;
-  const size_t plane_stride = (size_t)B * C8 * HWo;
   for (uint32_t base = blockIdx.x * blockDim.x; base < total; base += gridDim.x * blockDim.x) {
     const uint32_t idx = base + threadIdx.x;
     const uint32_t g0 = base / per_plane;                // first (image, channel-group) of this block iteration
@@ -499,10 +499,9 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_planes(
     const float* __restrict__ rstd, const float* __restrict__ gamma, const float* __restrict__ beta,
     const float* __restrict__ skip, const double* __restrict__ dsums, double count, float* __restrict__ dx,
     float* __restrict__ dskip, u32x4* __restrict__ planes, int B, int C, int H, int W, float slope, int w_shift,
-    BnBwdSumsIn sm) {
+    BnBwdSumsIn sm, size_t plane_stride) {
   __shared__ float s_m1[SUMS ? kStatCh : 1], s_m2[SUMS ? kStatCh : 1];
   const uint32_t HW = H * W, C8 = C >> 3, per_plane = HW / 4, total = (uint32_t)B * C8 * per_plane;
-  const size_t plane_stride = (size_t)B * C8 * HW;
   for (uint32_t base = blockIdx.x * blockDim.x; base < total; base += gridDim.x * blockDim.x) {
     const uint32_t idx = base + threadIdx.x;
     const uint32_t g0 = base / per_plane;
@@ -748,7 +747,7 @@ int itcv_bn_act_planes_supported(int C, int H, int W, int pool) {
 
 int itcv_bn_act_fwd(const float* x, const float* mean, const float* rstd, const float* gamma, const float* beta,
                     const float* skip, float* y, int B, int C, int H, int W, float slope, int pool, void* planes,
-                    int ns, void* stream) {
+                    int ns, size_t plane_stride, void* stream) {
   ITCV_REQUIRE(x && mean && rstd && gamma && beta && (y || planes) && B > 0 && C > 0 && H > 0 && W > 0, "itcv_bn_act_fwd");
   ITCV_REQUIRE((size_t)B * C * H * W < (1ull << 31), "itcv_bn_act_fwd(tensor < 2^31 elements)");
   if (planes) {
@@ -756,9 +755,10 @@ int itcv_bn_act_fwd(const float* x, const float* mean, const float* rstd, const 
     const size_t threads = (size_t)B * (C / 8) * ((pool ? (H / 2) * (W / 2) : H * W) / (pool ? 2 : 4));
     const dim3 grid(grid_for(threads)), blk(256);
     u32x4* pl = static_cast<u32x4*>(planes);
+    const size_t pstride = plane_stride ? plane_stride : (size_t)B * (C / 8) * (pool ? (H / 2) * (W / 2) : H * W);
 #define ITCV_FWD_PLANES(POOL_, NS_)                                                                                   \
   hipLaunchKernelGGL((bn_act_fwd_planes_kernel<POOL_, NS_, false>), grid, blk, 0, S(stream), x, mean, rstd, gamma, beta, \
-                     skip, y, pl, B, C, H, W, slope, BnStatsIn{})
+                     skip, y, pl, B, C, H, W, slope, BnStatsIn{}, pstride)
     if (pool) {
       if (ns == 2) ITCV_FWD_PLANES(1, 2);
       else ITCV_FWD_PLANES(1, 3);
@@ -830,9 +830,11 @@ int itcv_bn_act_bwd_reduce(const float* x, const float* dy, const float* mean, c
 int itcv_bn_act_bwd_apply(const float* x, const float* dy, const float* mean, const float* rstd, const float* gamma,
                           const float* beta, const float* skip, const double* dsums, const double* local_dsums,
                           double count, float* dx, float* dskip, float* dgamma, float* dbeta, int accumulate, int B,
-                          int C, int H, int W, float slope, int pool, int up2, void* dx_planes, int ns, void* stream) {
+                          int C, int H, int W, float slope, int pool, int up2, void* dx_planes, int ns,
+                          size_t plane_stride, void* stream) {
   ITCV_REQUIRE(x && dy && mean && rstd && gamma && beta && dsums && (dx || dx_planes) && B > 0 && C > 0 && count > 0,
                "itcv_bn_act_bwd_apply");
+  const size_t pstride = plane_stride ? plane_stride : (size_t)B * (C / 8) * H * W;
   ITCV_REQUIRE(!(pool && up2), "itcv_bn_act_bwd_apply(pool and up2 are exclusive)");
   const size_t n = (size_t)B * C * H * W;
   const bool vec = (W % 4 == 0) && (n < (1ull << 31));
@@ -844,7 +846,7 @@ int itcv_bn_act_bwd_apply(const float* x, const float* dy, const float* mean, co
     u32x4* pl = static_cast<u32x4*>(dx_planes);
 #define ITCV_BWD_PLANES(MODE_, NS_)                                                                              \
   hipLaunchKernelGGL((bn_bwd_apply_planes<MODE_, NS_, false>), grid, blk, 0, st, x, dy, mean, rstd, gamma, beta, skip,  \
-                     dsums, count, dx, dskip, pl, B, C, H, W, slope, wsh, BnBwdSumsIn{})
+                     dsums, count, dx, dskip, pl, B, C, H, W, slope, wsh, BnBwdSumsIn{}, pstride)
 #define ITCV_BWD_PLANES_NS(MODE_)        \
   do {                                   \
     if (ns == 2) ITCV_BWD_PLANES(MODE_, 2); \
@@ -894,8 +896,9 @@ int itcv_bn_act_bwd_apply(const float* x, const float* dy, const float* mean, co
 int itcv_bn_train_fwd(const float* x, const float* gamma, const float* beta, const float* skip, float* y, void* planes,
                       int ns, int B, int C, int H, int W, float slope, int pool, float eps, float momentum,
                       float* running_mean, float* running_var, int64_t* num_batches_tracked, float* mean, float* rstd,
-                      void* ws, size_t ws_bytes, void* stream) {
+                      void* ws, size_t ws_bytes, size_t plane_stride, void* stream) {
   ITCV_REQUIRE(x && gamma && beta && mean && rstd && (y || planes) && B > 0 && C > 0 && H > 0 && W > 0, "itcv_bn_train_fwd");
+  const size_t pstride = plane_stride ? plane_stride : (size_t)B * (C / 8) * (pool ? (H / 2) * (W / 2) : H * W);
   const int HW = H * W, splits = bn_splits(B, C, HW);
   const int per_plane = pool ? (HW / 4) / 2 : HW / 4;
   const bool fusable = planes && (ns == 2 || ns == 3) && itcv_bn_act_planes_supported(C, H, W, pool) && splits > 1 &&
@@ -904,7 +907,7 @@ int itcv_bn_train_fwd(const float* x, const float* gamma, const float* beta, con
     if (int e = itcv_bn_train_stats(x, B, C, HW, eps, momentum, running_mean, running_var, num_batches_tracked, mean,
                                     rstd, ws, ws_bytes, stream))
       return e;
-    return itcv_bn_act_fwd(x, mean, rstd, gamma, beta, skip, y, B, C, H, W, slope, pool, planes, ns, stream);
+    return itcv_bn_act_fwd(x, mean, rstd, gamma, beta, skip, y, B, C, H, W, slope, pool, planes, ns, plane_stride, stream);
   }
   ITCV_REQUIRE(ws && ws_bytes >= (size_t)splits * 2 * C * sizeof(double), "itcv_bn_train_fwd(workspace)");
   double* part = static_cast<double*>(ws);
@@ -917,7 +920,7 @@ int itcv_bn_train_fwd(const float* x, const float* gamma, const float* beta, con
   u32x4* pl = static_cast<u32x4*>(planes);
 #define ITCV_FWD_FUSED(POOL_, NS_)                                                                                   \
   hipLaunchKernelGGL((bn_act_fwd_planes_kernel<POOL_, NS_, true>), grid, blk, 0, S(stream), x, mean, rstd, gamma, beta, \
-                     skip, y, pl, B, C, H, W, slope, st)
+                     skip, y, pl, B, C, H, W, slope, st, pstride)
   if (pool) {
     if (ns == 2) ITCV_FWD_FUSED(1, 2);
     else ITCV_FWD_FUSED(1, 3);
@@ -933,7 +936,7 @@ int itcv_bn_train_fwd(const float* x, const float* gamma, const float* beta, con
 int itcv_bn_train_bwd(const float* x, const float* dy, const float* mean, const float* rstd, const float* gamma,
                       const float* beta, const float* skip, double* dsums, float* dx, float* dskip, void* dx_planes,
                       int ns, float* dgamma, float* dbeta, int accumulate, int B, int C, int H, int W, float slope,
-                      int pool, int up2, void* ws, size_t ws_bytes, void* stream) {
+                      int pool, int up2, void* ws, size_t ws_bytes, size_t plane_stride, void* stream) {
   ITCV_REQUIRE(x && dy && mean && rstd && gamma && beta && dsums && (dx || dx_planes) && B > 0 && C > 0,
                "itcv_bn_train_bwd");
   ITCV_REQUIRE(!(pool && up2), "itcv_bn_train_bwd(pool and up2 are exclusive)");
@@ -947,7 +950,7 @@ int itcv_bn_train_bwd(const float* x, const float* dy, const float* mean, const 
                                        slope, pool, up2, ws, ws_bytes, stream))
       return e;
     return itcv_bn_act_bwd_apply(x, dy, mean, rstd, gamma, beta, skip, dsums, nullptr, (double)B * HW, dx, dskip, nullptr,
-                                 nullptr, 0, B, C, H, W, slope, pool, up2, dx_planes, ns, stream);
+                                 nullptr, 0, B, C, H, W, slope, pool, up2, dx_planes, ns, plane_stride, stream);
   }
   if (pool) ITCV_REQUIRE(H % 2 == 0 && W % 2 == 0, "itcv_bn_train_bwd(pool)");
   ITCV_REQUIRE(ws && ws_bytes >= (size_t)splits * 2 * C * sizeof(double), "itcv_bn_train_bwd(workspace)");
@@ -958,12 +961,13 @@ int itcv_bn_train_bwd(const float* x, const float* dy, const float* mean, const 
   const dim3 rgrid(C, splits), agrid(grid_for(n / 32)), blk(256);
   u32x4* pl = static_cast<u32x4*>(dx_planes);
   const double count = (double)B * HW;
+  const size_t pstride = plane_stride ? plane_stride : (size_t)B * (C / 8) * HW;
 #define ITCV_BWD_FUSED(MODE_, NS_)                                                                                    \
   do {                                                                                                                \
     hipLaunchKernelGGL((bn_bwd_partial_v4<MODE_, false>), rgrid, dim3(kRedThreads), 0, st, x, dy, mean, rstd, gamma,   \
                        beta, skip, part, B, C, H, W, slope, splits, wsh, hwsh, BnBwdFinal{});                         \
     hipLaunchKernelGGL((bn_bwd_apply_planes<MODE_, NS_, true>), agrid, blk, 0, st, x, dy, mean, rstd, gamma, beta, skip, \
-                       static_cast<const double*>(nullptr), count, dx, dskip, pl, B, C, H, W, slope, wsh, sm);        \
+                       static_cast<const double*>(nullptr), count, dx, dskip, pl, B, C, H, W, slope, wsh, sm, pstride); \
   } while (0)
 #define ITCV_BWD_FUSED_NS(MODE_)            \
   do {                                      \

@@ -19,7 +19,7 @@ PKG_ROOT = os.path.dirname(_HERE)
 # ITCV_LIB: load another build of the same library (the -DITCV_DIAG diagnostic build of `make diag`, tools/abl.sh)
 LIB_PATH = os.environ.get("ITCV_LIB") or os.path.join(PKG_ROOT, "lib", "libitcv_hip.so")
 CSRC = os.path.join(PKG_ROOT, "csrc")
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 p, i32, i64, sz, f32, f64 = (ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_size_t,
                              ctypes.c_float, ctypes.c_double)
@@ -75,14 +75,14 @@ SIGNATURES = {
     "itcv_bn_finalize": (i32, [p, f64, f32, f32, p, p, p, p, p, i32, p]),
     "itcv_bn_eval_stats": (i32, [p, p, f32, p, p, i32, p]),
     "itcv_bn_act_planes_supported": (i32, [i32] * 4),
-    "itcv_bn_act_fwd": (i32, [p, p, p, p, p, p, p, i32, i32, i32, i32, f32, i32, p, i32, p]),
+    "itcv_bn_act_fwd": (i32, [p, p, p, p, p, p, p, i32, i32, i32, i32, f32, i32, p, i32, sz, p]),
     "itcv_bn_act_bwd_reduce": (i32, [p, p, p, p, p, p, p, p, p, p, i32, i32, i32, i32, i32, f32, i32, i32, p, sz,
                                      p]),
     "itcv_bn_act_bwd_apply": (i32, [p, p, p, p, p, p, p, p, p, f64, p, p, p, p, i32, i32, i32, i32, i32, f32,
-                                    i32, i32, p, i32, p]),
-    "itcv_bn_train_fwd": (i32, [p, p, p, p, p, p, i32, i32, i32, i32, i32, f32, i32, f32, f32, p, p, p, p, p, p, sz, p]),
+                                    i32, i32, p, i32, sz, p]),
+    "itcv_bn_train_fwd": (i32, [p, p, p, p, p, p, i32, i32, i32, i32, i32, f32, i32, f32, f32, p, p, p, p, p, p, sz, sz, p]),
     "itcv_bn_train_bwd": (i32, [p, p, p, p, p, p, p, p, p, p, p, i32, p, p, i32, i32, i32, i32, i32, f32, i32, i32, p,
-                                sz, p]),
+                                sz, sz, p]),
     "itcv_lrelu_fwd": (i32, [p, p, sz, f32, p]),
     "itcv_lrelu_bwd": (i32, [p, p, p, sz, f32, p]),
     "itcv_sigmoid_fwd": (i32, [p, p, sz, p]),

@@ -579,46 +579,59 @@ def _world(group):
 
 class BnActFn(Function):
     """y = pool(lrelu(BN_train(x) (+skip), slope)).  slope=1 -> plain BatchNorm; pool in {0,1}.
-    ``group``: process group for Sync-BN (moments all-reduced in fp64)."""
+    ``group``: process group for Sync-BN (moments all-reduced in fp64).
+    ``bn_groups`` = G > 1: the batch holds G independent network passes of B/G images each (the solvers push passes
+    that share their weights through the conv GEMMs as ONE batch); every pass is normalised with its own batch
+    statistics and advances the running buffers on its own, in order -- exactly G separate BatchNorm calls
+    (models.py:37-38), issued here as G launches on sub-batches of the same tensors."""
 
     @staticmethod
     def forward(ctx, x, gamma, beta, skip, running_mean, running_var, nbt, eps, momentum, slope, pool, training,
-                group, out_planes=0, grad_planes=0, out_fp32=True, grad_fp32=True):
+                group, out_planes=0, grad_planes=0, out_fp32=True, grad_fp32=True, bn_groups=1):
         x, gamma, beta = _f32c(x), _f32c(gamma), _f32c(beta)
         skip = None if skip is None else _f32c(skip)
         B, C, H, W = x.shape
+        G = int(bn_groups) if training else 1
+        if G < 1 or B % G:
+            raise abi.HipExtensionError(f"BatchNorm groups: batch {B} is not {G} equal passes")
+        Bg = B // G
         dev = x.device
-        mean = torch.empty((C,), dtype=F32, device=dev)
-        rstd = torch.empty((C,), dtype=F32, device=dev)
+        mean = torch.empty((G, C), dtype=F32, device=dev)
+        rstd = torch.empty((G, C), dtype=F32, device=dev)
         world = _world(group) if training else 1
         oshape = (B, C, H // 2, W // 2) if pool else (B, C, H, W)
         y = torch.empty(oshape, dtype=F32, device=dev)
-        yp = None
+        yp, pstride = None, 0
         if out_planes and lib.itcv_bn_act_planes_supported(C, H, W, int(pool)):
             yp = torch.empty(lib.itcv_planes_bytes(B, C, oshape[2] * oshape[3], out_planes) // 4, dtype=torch.int32,
                              device=dev)
+            pstride = B * (C // 8) * oshape[2] * oshape[3]            # chunks between planes of the WHOLE tensor
         write_y = out_fp32 or yp is None or _POISON[0]
-        if training and world == 1:
-            # statistics + apply in one call (the apply launch folds the sliced reduction where it can)
-            nws = lib.itcv_bn_workspace(B, C, H * W)
-            ws = _ws(nws, dev)
-            call("itcv_bn_train_fwd", ptr(x), ptr(gamma), ptr(beta), ptr(skip), ptr(y) if write_y else None, ptr(yp),
-                 int(out_planes), B, C, H, W, float(slope), int(pool), float(eps), float(momentum), ptr(running_mean),
-                 ptr(running_var), ptr(nbt), ptr(mean), ptr(rstd), ptr(ws), nws, stream())
-        else:
+        nws = lib.itcv_bn_workspace(Bg, C, H * W)
+        for g in range(G):
+            r = slice(g * Bg, (g + 1) * Bg)
+            xg, yg = x[r], (y[r] if write_y else None)
+            sg = None if skip is None else skip[r]
+            ypg = None if yp is None else yp[g * Bg * (C // 8) * oshape[2] * oshape[3] * 4:]    # int32 elements
+            if training and world == 1:
+                # statistics + apply in one call (the apply launch folds the sliced reduction where it can)
+                ws = _ws(nws, dev)
+                call("itcv_bn_train_fwd", ptr(xg), ptr(gamma), ptr(beta), ptr(sg), ptr(yg), ptr(ypg), int(out_planes), Bg,
+                     C, H, W, float(slope), int(pool), float(eps), float(momentum), ptr(running_mean), ptr(running_var),
+                     ptr(nbt), ptr(mean[g]), ptr(rstd[g]), ptr(ws), nws, pstride, stream())
+                continue
             if training:
-                nws = lib.itcv_bn_workspace(B, C, H * W)
                 ws = _ws(nws, dev)
                 sums = torch.empty((2 * C,), dtype=torch.float64, device=dev)
-                call("itcv_bn_moments", ptr(x), ptr(sums), B, C, H * W, ptr(ws), nws, stream())
+                call("itcv_bn_moments", ptr(xg), ptr(sums), Bg, C, H * W, ptr(ws), nws, stream())
                 dist.all_reduce(sums, group=group)
-                call("itcv_bn_finalize", ptr(sums), float(B * H * W * world), float(eps), float(momentum),
-                     ptr(running_mean), ptr(running_var), ptr(nbt), ptr(mean), ptr(rstd), C, stream())
+                call("itcv_bn_finalize", ptr(sums), float(Bg * H * W * world), float(eps), float(momentum),
+                     ptr(running_mean), ptr(running_var), ptr(nbt), ptr(mean[g]), ptr(rstd[g]), C, stream())
             else:
-                call("itcv_bn_eval_stats", ptr(running_mean), ptr(running_var), float(eps), ptr(mean), ptr(rstd), C,
+                call("itcv_bn_eval_stats", ptr(running_mean), ptr(running_var), float(eps), ptr(mean[g]), ptr(rstd[g]), C,
                      stream())
-            call("itcv_bn_act_fwd", ptr(x), ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), ptr(skip),
-                 ptr(y) if write_y else None, B, C, H, W, float(slope), int(pool), ptr(yp), int(out_planes), stream())
+            call("itcv_bn_act_fwd", ptr(xg), ptr(mean[g]), ptr(rstd[g]), ptr(gamma), ptr(beta), ptr(sg), ptr(yg), Bg, C, H, W,
+                 float(slope), int(pool), ptr(ypg), int(out_planes), pstride, stream())
         if yp is not None:
             if _POISON[0] and not out_fp32:
                 y.fill_(float("nan"))
@@ -628,7 +641,7 @@ class BnActFn(Function):
         if not lib.itcv_bn_act_planes_supported(C, H, W, 0):
             grad_planes = 0
         ctx.cfg = (B, C, H, W, float(slope), int(pool), bool(training), group, world, int(grad_planes),
-                   bool(grad_fp32) or not grad_planes)
+                   bool(grad_fp32) or not grad_planes, G)
         ctx.mark_non_differentiable(*[t for t in (running_mean, running_var, nbt) if t is not None])
         return y
 
@@ -636,14 +649,13 @@ class BnActFn(Function):
     @once_differentiable
     def backward(ctx, dy):
         x, gamma, beta, mean, rstd, skip = ctx.saved_tensors
-        B, C, H, W, slope, pool, training, group, world, grad_planes, grad_fp32 = ctx.cfg
+        B, C, H, W, slope, pool, training, group, world, grad_planes, grad_fp32, G = ctx.cfg
         if not training:
             raise abi.HipExtensionError("BatchNorm backward in eval mode is not part of the training hot path")
         dy = _f32c(dy)
         dev = x.device
-        nws = lib.itcv_bn_workspace(B, C, H * W)
-        ws = _ws(nws, dev)
-        local = torch.empty((2 * C,), dtype=torch.float64, device=dev)
+        Bg = B // G
+        nws = lib.itcv_bn_workspace(Bg, C, H * W)
         # parameter gradients come out of the reduce launch: either added straight into .grad
         # (solver mode) or into fresh tensors handed to autograd
         tg = _grad_target(gamma) if ctx.needs_input_grad[1] else None
@@ -651,34 +663,45 @@ class BnActFn(Function):
         direct = tg is not None and tb is not None
         dgamma = dbeta = None
         if direct:
-            pg, pb, acc = tg, tb, 1
+            pg, pb = tg, tb
         else:
             dgamma = torch.empty_like(gamma) if ctx.needs_input_grad[1] else None
             dbeta = torch.empty_like(beta) if ctx.needs_input_grad[2] else None
-            pg, pb, acc = dgamma, dbeta, 0
+            pg, pb = dgamma, dbeta
         dx = torch.empty_like(x)
         dskip = torch.empty_like(x) if (skip is not None and ctx.needs_input_grad[3]) else None
-        dxp = None
+        dxp, pstride = None, 0
         if grad_planes:
             dxp = torch.empty(lib.itcv_planes_bytes(B, C, H * W, grad_planes) // 4, dtype=torch.int32, device=dev)
+            pstride = B * (C // 8) * H * W
         write_dx = grad_fp32 or dxp is None or _POISON[0]
-        if world == 1:
-            call("itcv_bn_train_bwd", ptr(x), ptr(dy), ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), ptr(skip), ptr(local),
-                 ptr(dx) if write_dx else None, ptr(dskip), ptr(dxp), grad_planes, ptr(pg), ptr(pb), acc, B, C, H, W,
-                 slope, pool, 0, ptr(ws), nws, stream())
-        else:
-            call("itcv_bn_act_bwd_reduce", ptr(x), ptr(dy), ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), ptr(skip),
-                 ptr(local), ptr(pg), ptr(pb), acc, B, C, H, W, slope, pool, 0, ptr(ws), nws, stream())
-            total = local.clone()
-            dist.all_reduce(total, group=group)
-            call("itcv_bn_act_bwd_apply", ptr(x), ptr(dy), ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), ptr(skip),
-                 ptr(total), None, float(B * H * W * world), ptr(dx) if write_dx else None, ptr(dskip), None, None, 0, B,
-                 C, H, W, slope, pool, 0, ptr(dxp), grad_planes, stream())
+        for g in range(G):
+            r = slice(g * Bg, (g + 1) * Bg)
+            acc = 1 if (direct or g > 0) else 0       # the groups' parameter gradients add up
+            xg, dyg = x[r], dy[r]
+            sg = None if skip is None else skip[r]
+            dxg = dx[r] if write_dx else None
+            dsg = None if dskip is None else dskip[r]
+            dxpg = None if dxp is None else dxp[g * Bg * (C // 8) * H * W * 4:]
+            ws = _ws(nws, dev)
+            local = torch.empty((2 * C,), dtype=torch.float64, device=dev)
+            if world == 1:
+                call("itcv_bn_train_bwd", ptr(xg), ptr(dyg), ptr(mean[g]), ptr(rstd[g]), ptr(gamma), ptr(beta), ptr(sg),
+                     ptr(local), ptr(dxg), ptr(dsg), ptr(dxpg), grad_planes, ptr(pg), ptr(pb), acc, Bg, C, H, W,
+                     slope, pool, 0, ptr(ws), nws, pstride, stream())
+            else:
+                call("itcv_bn_act_bwd_reduce", ptr(xg), ptr(dyg), ptr(mean[g]), ptr(rstd[g]), ptr(gamma), ptr(beta), ptr(sg),
+                     ptr(local), ptr(pg), ptr(pb), acc, Bg, C, H, W, slope, pool, 0, ptr(ws), nws, stream())
+                total = local.clone()
+                dist.all_reduce(total, group=group)
+                call("itcv_bn_act_bwd_apply", ptr(xg), ptr(dyg), ptr(mean[g]), ptr(rstd[g]), ptr(gamma), ptr(beta), ptr(sg),
+                     ptr(total), None, float(Bg * H * W * world), ptr(dxg), ptr(dsg), None, None, 0, Bg, C, H, W, slope,
+                     pool, 0, ptr(dxpg), grad_planes, pstride, stream())
         if dxp is not None:
             if _POISON[0] and not grad_fp32:
                 dx.fill_(float("nan"))
             _tag_planes(dx, dxp, grad_planes, bool(grad_fp32))
-        return (dx, dgamma, dbeta, dskip) + (None,) * 13
+        return (dx, dgamma, dbeta, dskip) + (None,) * 14
 
 
 # ------------------------------------------------------------------ pointwise / resampling

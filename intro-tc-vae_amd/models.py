@@ -14,6 +14,7 @@ while ``self.main`` keeps the reference's child names (``main.0``, ``main.res_in
 and still works layer by layer (``fused = False``), which is what the parity tests compare the
 fused schedule against.  There is no CPU path: a CPU tensor raises in hipvae.abi.
 """
+import contextlib
 import math
 
 import torch
@@ -31,6 +32,25 @@ LRELU_SLOPE = 0.2
 # this flag is set the layers below run their torch parent classes on the CPU so that the same pass can be made
 # here (inception blocks: the biased 1x1 convs make the warm-up statistics weight dependent).  Never set in a step.
 _CPU_WARMUP = [False]
+
+
+# Number of independent network passes stacked in the batch of the current forward call (see bn_groups below)
+_BN_GROUPS = [1]
+
+
+@contextlib.contextmanager
+def bn_groups(groups):
+    """Inside this block a forward call treats its batch as ``groups`` independent passes of B/groups images each,
+    stacked along dim 0: the convolutions / linears see one large batch (the passes share their weights), every
+    BatchNorm layer normalises each pass with its OWN batch statistics and advances its running buffers once per
+    pass, in order -- numerically the same as ``groups`` separate forward calls (models.py:37-38), but each conv GEMM,
+    weight gradient and weight packing runs once on ``groups`` times the pixels.  The solvers use it for the passes of
+    a step that the reference issues back to back on the same weights (solvers/intro.py:70-86,119-134)."""
+    prev, _BN_GROUPS[0] = _BN_GROUPS[0], int(groups)
+    try:
+        yield
+    finally:
+        _BN_GROUPS[0] = prev
 
 
 def _add(a, b):
@@ -77,7 +97,7 @@ class HipBatchNorm2d(nn.BatchNorm2d):
         return HF.BnActFn.apply(x, self.weight, self.bias, skip, self.running_mean, self.running_var,
                                 self.num_batches_tracked, self.eps, self.momentum, slope, bool(pool), self.training,
                                 self.sync_group, int(out_mode[0]), int(grad_mode[0]), bool(out_mode[1]),
-                                bool(grad_mode[1]))
+                                bool(grad_mode[1]), _BN_GROUPS[0])
 
 
 class HipLeakyReLU(nn.LeakyReLU):

@@ -19,8 +19,18 @@ def traced_hip_step(solver, model, x, draws):
     per-tensor gradients of the trained half after each phase's backward (before the clip scales them)."""
     import ops
     tr = dict(decoded=[], encoded=[], kl=[], rec=[], grads=[])
-    h1 = model.decoder.register_forward_hook(lambda m, a, out: tr["decoded"].append(out.detach().cpu()))
-    h2 = model.encoder.register_forward_hook(lambda m, a, out: tr["encoded"].append(tuple(t.detach().cpu() for t in out)))
+    import models
+
+    # a batched pass (models.bn_groups) carries several of the reference's passes stacked along dim 0, in reference order
+    def dec_hook(m, a, out):
+        tr["decoded"] += [t.detach().cpu() for t in out.chunk(models._BN_GROUPS[0])]
+
+    def enc_hook(m, a, out):
+        G = models._BN_GROUPS[0]
+        tr["encoded"] += list(zip(*[[c.detach().cpu() for c in t.chunk(G)] for t in out]))
+
+    h1 = model.decoder.register_forward_hook(dec_hook)
+    h2 = model.encoder.register_forward_hook(enc_hook)
     kl0, rec0, clip0 = solver.compute_kl_loss, solver.compute_rec_loss, solver._clip
     solver.compute_kl_loss = lambda *a, **k: (tr["kl"].append(kl0(*a, **k)), tr["kl"][-1])[1]
     solver.compute_rec_loss = lambda *a, **k: (tr["rec"].append(rec0(*a, **k)), tr["rec"][-1])[1]
