@@ -449,3 +449,64 @@ def test_prefetch_loader_equals_direct_feeding(graph):
     loader = PrefetchLoader(dl, None, depth=2)
     got = torch.cat([b[0].cpu() for b in loader] + [b[0].cpu() for b in loader])
     assert torch.equal(got, torch.cat([images, images]))
+
+
+@pytest.mark.parametrize("arch", ["conv", "res", "inception"])
+def test_bn_groups_model_pass_equals_separate_passes(arch):
+    """models.bn_groups(2): one forward of two stacked batches == two forwards (outputs, running buffers, parameter
+    gradients), for every block architecture, fused and layer-by-layer schedules."""
+    import models
+    g = np.load(os.path.join(GOLDEN, f"model_{arch}.npz"))
+    gen = torch.Generator().manual_seed(5)
+    xa, xb = torch.rand(4, 3, 32, 32, generator=gen).to(dev()), torch.rand(4, 3, 32, 32, generator=gen).to(dev())
+    probe = torch.randn(8, 3, 32, 32, generator=gen).to(dev())
+    for fused in (True, False):
+        res = {}
+        for mode in ("stacked", "separate"):
+            model = build(arch, load_state(g, "init:")).set_fused(fused)
+            if mode == "stacked":
+                with models.bn_groups(2):
+                    mu, lv = model.encode(torch.cat([xa, xb]))
+                    rec = model.decode(mu)
+            else:
+                outs = [model.encode(t) for t in (xa, xb)]
+                mu, lv = torch.cat([o[0] for o in outs]), torch.cat([o[1] for o in outs])
+                rec = torch.cat([model.decode(o[0]) for o in outs])
+            ((rec * probe).sum() + lv.sum()).backward()
+            res[mode] = (mu.detach(), rec.detach(), {k: v.clone() for k, v in model.state_dict().items()},
+                         {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None})
+        s, r = res["stacked"], res["separate"]
+        assert rel_err(s[0], r[0]) < 1e-6 and rel_err(s[1], r[1]) < 1e-6
+        for k, v in r[2].items():
+            if "running" in k or "num_batches" in k:
+                assert rel_err(s[2][k].float(), v.float()) < 1e-6, k
+        assert s[3].keys() == r[3].keys()
+        for k, v in r[3].items():
+            assert rel_err(s[3][k], v) < 2e-5, k
+
+
+def test_batched_passes_equal_unbatched_step():
+    """IntroTCSovler with batch_passes (7 batched passes) == the 13 passes issued one by one: two steps, every returned
+    scalar and the final weights (the weight-gradient sums associate differently: 1e-5, weights 1e-6)."""
+    import ops
+    g = np.load(os.path.join(GOLDEN, "steps_conv.npz"))
+    hp = g["hp"]
+    out = {}
+    for batched in (True, False):
+        model = build("conv", load_state(g, "init:"))
+        solver = make_solver("intro_tc", model, hp)
+        solver.batch_passes = batched
+        res = []
+        for s in range(2):
+            p = f"intro_tc:s{s}:"
+            with ops.noise_queue([T(g[p + f"draw{i}"]) for i in range(6)]):
+                res.append(solver.train_step(T(g[f"x{s}"]), s))
+        out[batched] = (res, torch.cat([p.detach().reshape(-1) for p in model.parameters()]).cpu(),
+                        {k: v.clone().cpu() for k, v in model.state_dict().items() if "running" in k})
+    for a, b in zip(out[True][0], out[False][0]):
+        for k in a:
+            assert abs(a[k] - b[k]) <= 1e-5 * abs(b[k]), (k, a[k], b[k])
+    assert float((out[True][1] - out[False][1]).abs().max()) < 2.05 * 2e-4 * 2
+    assert float(((out[True][1] - out[False][1]).abs() > 1e-6).float().mean()) < 1e-3
+    for k, v in out[False][2].items():
+        assert rel_err(out[True][2][k], v) < 1e-5, k

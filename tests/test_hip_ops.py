@@ -207,7 +207,7 @@ def test_bn_upsampled_gradient_mode(HF):
              None, None, 0, B, C, H, W, 0.2, 0, up2, ptr(ws), nws, stream())
         dx = torch.empty_like(x)
         call("itcv_bn_act_bwd_apply", ptr(x), ptr(dy), ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), None, ptr(sums),
-             None, float(B * H * W), ptr(dx), None, None, None, 0, B, C, H, W, 0.2, 0, up2, None, 0, stream())
+             None, float(B * H * W), ptr(dx), None, None, None, 0, B, C, H, W, 0.2, 0, up2, None, 0, 0, stream())
         outs.append((sums.clone(), dx))
     assert rel_err(outs[0][0], outs[1][0]) < 1e-6
     assert rel_err(outs[0][1], outs[1][1]) < 1e-5
@@ -405,3 +405,50 @@ def test_errors_are_loud():
     with pytest.raises(RuntimeError):
         abi.call("itcv_conv2d_pack_weight", None, None, 1, 1, 7, 0, None)
     assert "itcv_conv2d_pack_weight" in abi.last_error()
+
+
+@pytest.mark.parametrize("pool", [False, True])
+@pytest.mark.parametrize("planes", [0, 2])
+def test_bn_groups_equal_separate_passes(HF, pool, planes):
+    """BatchNorm groups (models.bn_groups): one call on G stacked passes == G separate calls -- outputs, the planes
+    handed to the consumer conv, running buffers (advanced once per pass, in order), and every gradient, bit for bit
+    (the same kernels run on the same sub-batches)."""
+    G, Bg, C, H, W = 2, 6, 16, 8, 8
+    g = torch.Generator().manual_seed(31)
+    d = dev()
+    x = (torch.randn(G * Bg, C, H, W, generator=g) * 1.5 + 0.3).to(d)
+    gamma, beta = (torch.rand(C, generator=g) + 0.5).to(d), torch.randn(C, generator=g).to(d)
+    oshape = (G * Bg, C, H // 2, W // 2) if pool else (G * Bg, C, H, W)
+    dy = torch.randn(*oshape, generator=g).to(d)
+
+    def run(groups):
+        rm, rv, nbt = torch.zeros(C, device=d), torch.ones(C, device=d), torch.zeros((), dtype=torch.long, device=d)
+        xs, ga, be = x.clone().requires_grad_(True), gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+        if groups > 1:
+            y = HF.BnActFn.apply(xs, ga, be, None, rm, rv, nbt, 1e-4, 0.1, 0.2, pool, True, None, planes, planes, True, True, groups)
+            pl = HF._tagged_planes(y, planes) if planes else None
+        else:
+            ys, pls = [], []
+            for k in range(G):
+                yk = HF.BnActFn.apply(xs[k * Bg:(k + 1) * Bg], ga, be, None, rm, rv, nbt, 1e-4, 0.1, 0.2, pool, True, None,
+                                      planes, planes, True, True, 1)
+                ys.append(yk)
+                pls.append(HF._tagged_planes(yk, planes) if planes else None)
+            y, pl = torch.cat(ys), pls
+        y.backward(dy)
+        return y.detach(), pl, rm, rv, int(nbt), xs.grad, ga.grad, be.grad
+
+    a, b = run(G), run(1)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[2], b[2]) and torch.equal(a[3], b[3]) and a[4] == b[4] == G
+    assert torch.equal(a[5], b[5])
+    assert rel_err(a[6], b[6]) < 1e-6 and rel_err(a[7], b[7]) < 1e-6     # two fp32 additions in a different grouping
+    if planes:
+        # planes of the batched tensor: [plane][image][c/8][hw]; a pass's planes are a sub-range of every plane
+        n_img = C // 8 * oshape[2] * oshape[3] * 4           # int32 words per image per plane
+        whole = a[1].view(planes, G * Bg, n_img)
+        for k in range(G):
+            assert torch.equal(whole[:, k * Bg:(k + 1) * Bg], b[1][k].view(planes, Bg, n_img))
+    # statistics really are per pass: a single-group call on the stacked batch differs
+    rm, rv, nbt = torch.zeros(C, device=d), torch.ones(C, device=d), torch.zeros((), dtype=torch.long, device=d)
+    y1 = HF.BnActFn.apply(x, gamma, beta, None, rm, rv, nbt, 1e-4, 0.1, 0.2, pool, True, None)
+    assert not torch.equal(y1, a[0])
