@@ -185,6 +185,9 @@ def roofline_of(records, math, steps, eager_elapsed, where):
         "algorithmic_gflop_per_launch": round(dom[1] / dom[0] * 1e-9, 3),
         "all_conv_kernels": {"achieved": round(conv_flop / conv_time * 1e-12, 2),
                              "share_of_eager_step_time": round(conv_time / eager_elapsed, 3)},
+        "buckets": [{"kernel": k, "ms_per_step": round(b[2] / steps * 1e3, 3), "launches_per_step": b[0] / steps,
+                     "tflops": round(b[1] / b[2] * 1e-12, 1)}
+                    for k, b in sorted(buckets.items(), key=lambda kv: -kv[1][2])[:14]],
         "measured": "HIP event pairs stamped at kernel start/end (hipExtLaunchKernelGGL inside libitcv_hip.so, launch "
                     f"stream) for every main conv kernel during {steps} eager steps of this workload, same process; they "
                     "include the end-of-kernel L2 write-back of the result, which rocprofv3's dispatch timestamps do not "

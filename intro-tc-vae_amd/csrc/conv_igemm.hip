@@ -22,34 +22,11 @@
 // half-wave (conflict free); operand fragments are double-buffered in registers across the
 // K-steps.  Global->register->LDS software pipeline with two LDS buffers and one barrier per
 // K-tile.  blockIdx -> tile mapping keeps tiles that share an im2col panel on one XCD.
-#include <stdlib.h>
-
-#include "common.h"
+#include "conv_shared.h"
 
 namespace itcv {
 
-// Diagnostic instrumentation (operand ablation, in-kernel cycle stamps) exists only in -DITCV_DIAG builds
-// (`make diag`, used by tools/abl.sh): in the shipped library the tests below are the constant 0, the branches are
-// compiled out and no environment variable can alter results.
-#ifdef ITCV_DIAG
-#define ITCV_ABL(args, bits) (((args).ablate & (bits)) != 0)
-#define ITCV_DBG(args) ((args).debug != 0)
-static int diag_ablate() {
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("ITCV_ABLATE");
-    v = e ? atoi(e) : 0;
-  }
-  return v;
-}
-#else
-#define ITCV_ABL(args, bits) (false)
-#define ITCV_DBG(args) (false)
-#endif
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x4_t __attribute__((ext_vector_type(4)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr uint32_t kOobBase = 0x80000000u;  // + any soffset < 2^31 stays out of range
 
@@ -367,25 +344,6 @@ __global__ void pack_weight_kernel(const float* __restrict__ w, float* __restric
 // Same tap-major K order (32 channels of one tap per K-tile), same tile/XCD mapping and epilogue as
 // the fp32 kernel.  LDS holds 16-byte chunks [plane][k/8][row] so that every MFMA fragment is one
 // conflict-free ds_read_b128.
-
-// LDS-DMA of one 16-byte chunk per lane (global -> LDS at lds_base + lane*16), issued as raw ISA: the
-// compiler's own tracking of the builtin puts an `s_waitcnt vmcnt(0)` in front of EVERY later ds_read
-// (it cannot tell the ring slots apart), which serialises the prefetch with the tile being computed.
-// The caller orders the reads by hand (s_waitcnt vmcnt(N) + barrier).
-#pragma clang diagnostic ignored "-Winline-asm"   // m0 is a reserved register: named so the compiler re-materialises it
-__device__ __forceinline__ void lds_dma16(const void* gptr, uint32_t lds_base) {
-  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off"
-               :
-               : "s"(__builtin_amdgcn_readfirstlane(lds_base)), "v"(gptr)
-               : "memory", "m0");
-}
-__device__ __forceinline__ uint32_t lds_addr(const void* p) {
-  return (uint32_t)(size_t)(const __attribute__((address_space(3))) void*)p;
-}
-template <int N>
-__device__ __forceinline__ void wait_vmcnt() {
-  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
-}
 
 struct ConvArgsB {
   const float* x;
@@ -1011,259 +969,6 @@ __global__ __launch_bounds__(512) void conv_fwd_bf16p_kernel(ConvArgsP a) {
   }
 }
 
-// ---- second form of the planes kernel: tap reuse through LDS ---------------------------------------
-// conv_fwd_bf16p_kernel fetches every input chunk nine times (once per tap) and its weight tile once per
-// 128 pixels; measured, the L2 -> LDS ingest (~30 B/clk/CU) then takes as long as the MFMAs.  Here a block
-// owns 256 consecutive pixels (a band of whole image rows) x BM output channels:
-//   * per 32-channel group the band arrives ONCE, with its halo (rows -1..NR, columns -1..W, zero chunks
-//     outside the image), double-buffered; the nine taps read it at fragment addresses shifted by
-//     dh*(W+2)+dw chunks -- no per-tap traffic at all;
-//   * the weight tile of each (group, tap) streams through a 3-slot ring and serves twice the pixels;
-//   * 8 MFMA waves (two per SIMD, so one fills the other's barrier / LDS-latency bubbles) + 4 loader waves.
-// Ingest per MFMA drops ~2.8x.  Same arithmetic and K order as the other split-bf16 kernels (bit-identical).
-struct ConvArgsP2 {
-  const u32x4* xp;
-  const u32x4* wp;
-  const float* bias;
-  float* y;
-  int B, Ci, H, Co;
-  int Mp, N;
-  int mt, nt;
-  int cpt, cpt_per_split;        // 32-channel groups, and how many of them one split-K slice takes
-  int SR, NSEG, NP, NPC, PXB;    // band geometry: segment rows, segments, halo pixels, 64-chunk pieces, LDS row stride
-  int h_shift;
-  size_t slab_stride, plane_stride;
-#ifdef ITCV_DIAG
-  int debug;   // diagnostic only (ITCV_ABLATE & 64): block 0 / 100 report main-loop shader cycles and 100 MHz ticks in y[0..3]
-#endif
-};
-
-template <int LOG2W, int BM, bool UP2>
-__global__ __launch_bounds__(768) void conv_fwd_bf16p2_kernel(ConvArgsP2 a) {
-  constexpr int W = 1 << LOG2W, WP = W + 2, BN = 256, KC = 4, NS = 2;
-  constexpr int WM = BM / 64, WN = 8 / WM, WTN = BN / WN, TM = 2, TN = WTN / 32;   // 128: 2x4 waves of 64x64; 64: 1x8 of 64x32
-  constexpr int ASZ = NS * KC * BM;                // chunks per weight tile
-  constexpr int PA = NS * KC * BM / 64 / 4;        // weight pieces per loader wave per K-tile
-  // G K-tiles (taps) per barrier: the 64-row tiles do half the MFMA work per K-tile, so they take two taps per
-  // stage (the block-wide barrier and the LDS latency behind it were ~40 % of their K-tile time)
-  constexpr int G = BM == 64 ? 2 : 1, NSTG = (9 + G - 1) / G;
-  extern __shared__ u32x4 smem[];                  // [3][G][ASZ] weight ring, then [2][NS*KC*PXB] bands
-
-  const int t = threadIdx.x, lane = t & 63;
-  const int wid = __builtin_amdgcn_readfirstlane(t >> 6);
-  const int bid = blockIdx.x, xcd = bid & 7, q = bid >> 3;
-  const int tile_m = q % a.mt, tile_n = (q / a.mt) * 8 + xcd;
-  if (tile_n >= a.nt) return;
-  const int sk = blockIdx.y;
-  const int c0 = sk * a.cpt_per_split, c1 = min(a.cpt, c0 + a.cpt_per_split);
-  if (c0 >= c1) return;
-  const int nk = (c1 - c0) * 9;
-  const int m0 = tile_m * BM, n0 = tile_n * BN;
-  const int H = a.H, HW = H << LOG2W;
-  const int PXB = a.PXB, BSZ = NS * KC * PXB;
-  const uint32_t smem_base = lds_addr(smem);
-  const uint32_t band_base = smem_base + 3u * G * ASZ * 16u;
-
-  if (wid >= 8) {
-    // ------------------------------------------------------------------ loaders
-    const int lw = wid - 8;
-    const int Hs = UP2 ? H / 2 : H, Ws = UP2 ? W / 2 : W, HWs = Hs * Ws;
-    const int C8 = a.Ci >> 3;
-    const u32x4* zero = &g_zero_chunk;
-    // band pieces of this wave: rows pk = lw (plane 0, kc = lw) and lw + 4 (plane 1), halo pixels q*64 + lane
-    const int R0 = n0 >> LOG2W, seg_px = (a.SR + 2) * WP;
-    long long soff[8];
-    uint32_t vmask = 0;
-#pragma unroll
-    for (int qq = 0; qq < 8; ++qq) {
-      const int hp = qq * 64 + lane;   // lanes past NP land in the row's padding (PXB = NPC*64) and read zeros
-      soff[qq] = 0;
-      if (qq < a.NPC && hp < a.NP) {
-        const int seg = hp / seg_px, rem = hp - seg * seg_px, hr = rem / WP, hc = rem - hr * WP;
-        const int grow = R0 + seg * a.SR, b = grow >> a.h_shift, h = (grow & (H - 1)) + hr - 1, wv = hc - 1;
-        if (b < a.B && (unsigned)h < (unsigned)H && (unsigned)wv < (unsigned)W) {
-          vmask |= 1u << qq;
-          soff[qq] = (long long)b * C8 * HWs + (UP2 ? (h >> 1) * Ws + (wv >> 1) : h * W + wv);
-        }
-      }
-    }
-    // every wave instruction below is issued by all 64 lanes (never skipped): the counted vmcnt waits rely on it
-    auto issue_band_piece = [&](int cib, int buf, long long so, bool valid, int qq) {
-#pragma unroll
-      for (int pl = 0; pl < NS; ++pl) {
-        const u32x4* src = a.xp + ((size_t)pl * a.plane_stride + (size_t)(cib * KC + lw) * HWs + so);
-        lds_dma16(valid ? src : zero, band_base + (uint32_t)(buf * BSZ + (pl * KC + lw) * PXB + qq * 64) * 16u);
-      }
-    };
-    auto issue_A = [&](int i, int slot) {   // weight tile of K-tile i of this slice
-      const int kt = c0 * 9 + i;
-      const u32x4* wt = a.wp + (size_t)kt * NS * KC * a.Mp + m0 + lane;
-      const uint32_t sbase = smem_base + (uint32_t)(slot * ASZ) * 16u;
-#pragma unroll
-      for (int j = 0; j < PA; ++j) {
-        const int piece = j * 4 + lw, mlc = piece % (BM / 64), pk = piece / (BM / 64);
-        lds_dma16(wt + (size_t)pk * a.Mp + mlc * 64, sbase + (uint32_t)(pk * BM + mlc * 64) * 16u);
-      }
-    };
-    // weight tiles of one stage (taps st*G .. of group cib) -> ring slot `slot`; past the end of the slice the last
-    // K-tile is fetched again (same instruction count: the counted waits stay valid)
-    auto issue_stage_A = [&](int cib, int st, int slot) {
-#pragma unroll
-      for (int u = 0; u < G; ++u)
-        if (st * G + u < 9) issue_A(min((cib - c0) * 9 + st * G + u, nk - 1), slot * G + u);
-    };
-    auto stage_taps = [](int st) { return (st * G + G <= 9) ? G : 9 - st * G; };
-#pragma unroll
-    for (int qq = 0; qq < 8; ++qq)
-      if (qq < a.NPC) issue_band_piece(c0, 0, soff[qq], (vmask >> qq) & 1u, qq);
-    issue_stage_A(c0, 0, 0);
-    issue_stage_A(c0, 1, 1);
-    wait_vmcnt<PA * (NSTG > 1 ? ((1 * G + G <= 9) ? G : 9 - G) : 0)>();   // band and stage 0 landed; stage 1 may be in flight
-    __builtin_amdgcn_s_barrier();
-    int buf = 0, slot = 2;
-    for (int cib = c0; cib < c1; ++cib) {
-#pragma unroll
-      for (int st = 0; st < NSTG; ++st) {
-        const int st2 = (st + 2) % NSTG, cib2 = cib + (st + 2) / NSTG;
-        issue_stage_A(cib2, st2, slot);                       // into the slot stage S-1 has just left
-        if (++slot == 3) slot = 0;
-        // next group's band, one piece (x 2 planes) per tap of this stage
-        int nb = 0;
-#pragma unroll
-        for (int u = 0; u < G; ++u) {
-          const int tap = st * G + u;
-          if (tap < 8 && tap < a.NPC && cib + 1 < c1) {
-            issue_band_piece(cib + 1, buf ^ 1, soff[tap < 8 ? tap : 0], (vmask >> tap) & 1u, tap);
-            ++nb;
-          }
-        }
-        // stage S+1's weights (and everything older) have landed: only this iteration's loads may be in flight
-        const int na = stage_taps(st2);
-        if (na == G) {
-          if (nb == 0) wait_vmcnt<PA * G>();
-          else if (nb == 1) wait_vmcnt<PA * G + NS>();
-          else wait_vmcnt<PA * G + 2 * NS>();
-        } else {
-          if (nb == 0) wait_vmcnt<PA*(9 % G ? 9 % G : G)>();
-          else if (nb == 1) wait_vmcnt<PA*(9 % G ? 9 % G : G) + NS>();
-          else wait_vmcnt<PA*(9 % G ? 9 % G : G) + 2 * NS>();
-        }
-        __builtin_amdgcn_s_barrier();
-      }
-      buf ^= 1;
-    }
-    return;
-  }
-
-  // -------------------------------------------------------------------- MFMA waves
-  const int wm = wid / WN, wn = wid % WN, l31 = lane & 31, half = lane >> 5;
-  // band index of this lane's pixel of N-tile j (centre tap)
-  uint32_t hoff[TN];
-#pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    const int nl = wn * WTN + j * 32 + l31, R = nl >> LOG2W, w = nl & (W - 1);
-    const int seg = R / a.SR, rr = R - seg * a.SR;
-    hoff[j] = (uint32_t)((seg * (a.SR + 2) + rr + 1) * WP + w + 1) * 16u;
-  }
-  const uint32_t aoff = (uint32_t)(wm * 64 + l31) * 16u;
-  f32x16 acc[TM][TN];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-  const long long dbg_c00 = ITCV_DBG(a) ? clock64() : 0;
-  __builtin_amdgcn_s_barrier();
-  int buf = 0;
-  const long long dbg_c0 = ITCV_DBG(a) ? clock64() : 0, dbg_w0 = ITCV_DBG(a) ? wall_clock64() : 0;
-  int slot = 0;
-  for (int cib = c0; cib < c1; ++cib) {
-    const uint32_t bb = band_base + (uint32_t)(buf * BSZ) * 16u;
-#pragma unroll
-    for (int st = 0; st < NSTG; ++st) {
-#pragma unroll
-      for (int u = 0; u < G; ++u) {
-        const int tap = st * G + u;
-        if (tap >= 9) continue;
-        const int tapoff = ((tap / 3 - 1) * WP + (tap % 3 - 1)) * 16;
-        const uint32_t ab = smem_base + (uint32_t)((slot * G + u) * ASZ) * 16u + aoff;
-        // all fragments of the K-tile (both 16-wide k-steps) are requested up front and the scheduler is told to
-        // interleave: the first k-step's reads, then one read of the second k-step behind each of the first MFMAs --
-        // left alone it parks most reads directly in front of their use (`s_waitcnt lgkmcnt(0)` before the MFMA)
-        bf16x8 af[2][NS][TM], bfr[2][NS][TN];
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-          const int kc = ks * 2 + half;
-#pragma unroll
-          for (int pp = 0; pp < NS; ++pp) {
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-              af[ks][pp][i] = __builtin_bit_cast(
-                  bf16x8, *(const __attribute__((address_space(3))) u32x4*)(size_t)(ab + (uint32_t)(((pp * KC + kc) * BM + i * 32) * 16)));
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-              bfr[ks][pp][j] = __builtin_bit_cast(
-                  bf16x8, *(const __attribute__((address_space(3))) u32x4*)(size_t)(bb + (uint32_t)((pp * KC + kc) * PXB) * 16u + hoff[j] + tapoff));
-          }
-        }
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-          for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-              f32x16 c = acc[i][j];
-              c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks][0][i], bfr[ks][1][j], c, 0, 0, 0);
-              c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks][1][i], bfr[ks][0][j], c, 0, 0, 0);
-              c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks][0][i], bfr[ks][0][j], c, 0, 0, 0);
-              acc[i][j] = c;
-            }
-        {
-          constexpr int RD = NS * (TM + TN), MF = TM * TN * 3;   // LDS reads / MFMAs per k-step
-          __builtin_amdgcn_sched_group_barrier(0x100, RD, 0);
-#pragma unroll
-          for (int r = 0; r < RD; ++r) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-          }
-          __builtin_amdgcn_sched_group_barrier(0x008, 2 * MF - RD, 0);
-        }
-      }
-      if (++slot == 3) slot = 0;
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-    }
-    buf ^= 1;
-  }
-  if (ITCV_DBG(a) && t == 0 && (bid == 0 || bid == 100)) {
-    float* d = a.y + (bid ? 4 : 0);
-    d[0] = (float)(clock64() - dbg_c0), d[1] = (float)(wall_clock64() - dbg_w0), d[2] = (float)(dbg_c0 - dbg_c00), d[3] = (float)nk;
-    return;
-  }
-
-  float* out = a.y + (size_t)sk * a.slab_stride;
-#pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    const int nn = n0 + wn * WTN + j * 32 + l31;
-    if (nn >= a.N) continue;
-    const int b2 = nn / HW, hw2 = nn - b2 * HW;
-    const size_t base = (size_t)b2 * a.Co * HW + hw2;
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-        if (m < a.Co) {
-          float v = acc[i][j][r];
-          if (a.bias) v += a.bias[m];
-          out[base + (size_t)m * HW] = v;
-        }
-      }
-    }
-  }
-}
-
 // fp32 NCHW -> planes[p][b][c/8][hw] (C % 8 == 0); one thread per chunk, coalesced over hw
 template <int NS>
 __global__ void split_planes_kernel(const float* __restrict__ x, u32x4* __restrict__ planes, int B, int C8, int HW) {
@@ -1659,6 +1364,7 @@ struct WgradArgsP {
   int tiles_m, tiles_n;
   int steps, steps_per_split, splits;
   int h_shift;
+  int wseg_shift;           // images wider than 64 (LOG2W = 6 instantiation): log2(W / 64) 64-pixel segments per row
   size_t xplane, dyplane;   // chunks per plane
 #ifdef ITCV_DIAG
   int debug;                // diagnostic only (ITCV_ABLATE & 64): block 0 reports main-loop shader cycles / steps in slab[0..1]
@@ -1695,21 +1401,25 @@ __global__ __launch_bounds__(512 + 64 * NLW) void conv_wgrad_bf16p_kernel(WgradA
   const int tn = bid % a.tiles_n, tm = bid / a.tiles_n;
   const int co0 = tm * BM, ci0 = tn * BN;
   const int s0 = split * a.steps_per_split, s1 = min(a.steps, s0 + a.steps_per_split);
-  const int H = a.H, HW = H * W;
+  // Image width: the band (one step = 64 pixels = NR rows of W <= 64 columns) is the image row for LOG2W < 6; the
+  // LOG2W = 6 instantiation also serves 128- and 256-wide images, one 64-column SEGMENT of a row per step
+  // (the segment's halo columns come from the neighbouring segments instead of the zero padding)
+  const int wsh = LOG2W == 6 ? a.wseg_shift : 0;
+  const int Wi = W << wsh;
+  const int H = a.H, HW = H * Wi;
   const uint32_t smem_base = lds_addr(smem);
 
   if (wid >= 8) {
     // ------------------------------------------------------------------ loaders
     if (s0 >= s1) return;
     const int lw = wid - 8;
-    const int Hs = UP2 ? H / 2 : H, Ws = UP2 ? W / 2 : W, HWs = Hs * Ws;
+    const int Hs = UP2 ? H / 2 : H, Ws = UP2 ? Wi / 2 : Wi, HWs = Hs * Ws;
     const int Co8 = a.Co >> 3, Ci8 = a.Ci >> 3, dh = dhi - 1;
     const u32x4* zero = &g_zero_chunk;
     // this wave's band pixel (same for all of its X pieces): half = lw & 1
     const int hp = (lw & 1) * 64 + lane;
     const bool hp_active = hp < NP;
-    const int R = hp / WP, w = hp - R * WP - 1;
-    const bool w_ok = (unsigned)w < (unsigned)W;
+    const int R = hp / WP, w = hp - R * WP - 1;     // column inside the band: -1 .. W
 
     auto issue = [&](int st, int stage) {
       const uint32_t sbase = smem_base + (uint32_t)(stage * SSZ) * 16u;
@@ -1726,9 +1436,10 @@ __global__ __launch_bounds__(512 + 64 * NLW) void conv_wgrad_bf16p_kernel(WgradA
       }
       // X band: rows st*NR .. st*NR+NR-1 of the (batch x height) row index, shifted by dh; 2 pieces per (plane, chunk row)
       {
-        const int gr = st * NR + R, b = gr >> a.h_shift, h = gr & (H - 1), hh = h + dh;
-        const bool valid = w_ok && (unsigned)hh < (unsigned)H;
-        const int spix = UP2 ? (hh >> 1) * Ws + (w >> 1) : hh * W + w;
+        const int gr = (st >> wsh) * NR + R, b = gr >> a.h_shift, h = gr & (H - 1), hh = h + dh;
+        const int wi = ((st & ((1 << wsh) - 1)) << 6) + w;     // image column (wsh = 0: the band is the whole row)
+        const bool valid = (unsigned)wi < (unsigned)Wi && (unsigned)hh < (unsigned)H;
+        const int spix = UP2 ? (hh >> 1) * Ws + (wi >> 1) : hh * Wi + wi;
 #pragma unroll
         for (int j = 0; j < 4 * BCH / NLW; ++j) {
           const int qq = (j * NLW + lw) >> 1, pl = qq / BCH, c8 = qq % BCH;
@@ -2113,12 +1824,6 @@ __global__ void bias_grad_combine(const double* __restrict__ part, float* __rest
 
 // ------------------------------------------------------------------------------ host side
 static inline int pad16(int c) { return (c + 15) & ~15; }
-static inline int log2_exact(int v) {
-  if (v <= 0 || (v & (v - 1))) return -1;
-  int s = 0;
-  while ((1 << s) < v) ++s;
-  return s;
-}
 
 struct FwdPlan {
   int bm, bn, mt, nt, cip, ktiles, splits, kps;
@@ -2342,90 +2047,6 @@ static void launch_fwd_p(const ConvArgsP& a, int bm, int splits, int up2, hipStr
     }
   }
   launch_fwd_p_st<KS, NS, 2>(a, bm, splits, up2, st);
-}
-
-struct FwdPlanP2 {
-  int ok, bm, mt, nt, cpt, splits, cps, SR, NSEG, NP, NPC, PXB;
-  size_t lds;
-};
-static int p2_bm64_mid() {   // ITCV_P2_BM64=0: keep the 128-pixel-tile kernel for the mid-sized layers (diagnostic)
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("ITCV_P2_BM64");
-    v = (e && e[0] == '0') ? 0 : 1;
-  }
-  return v;
-}
-static FwdPlanP2 plan_fwd_p2(int B, int Ci, int H, int W, int Co, int KS, int ns) {
-  FwdPlanP2 p;
-  memset(&p, 0, sizeof(p));
-  const int lw = log2_exact(W), lh = log2_exact(H);
-  if (KS != 3 || ns != 2 || lw < 3 || lw > 6 || lh < 0 || Ci % 32 || Co < 33) return p;
-  static int enabled = -1;
-  if (enabled < 0) {
-    const char* e = getenv("ITCV_BF16P2");
-    enabled = (e && e[0] == '0') ? 0 : 1;
-  }
-  if (!enabled) return p;
-  const int NR = 256 / W;
-  p.SR = NR < H ? NR : H;
-  p.NSEG = NR / p.SR;
-  p.NP = p.NSEG * (p.SR + 2) * (W + 2);
-  p.NPC = cdiv(p.NP, 64);
-  p.PXB = p.NPC * 64;
-  if (p.NPC > 7) return p;
-  p.nt = (int)(((long long)B * H * W + 255) / 256);
-  p.bm = Co <= 64 ? 64 : 128;
-  // mid-sized layers: 64-row tiles when that fills the chip without split-K and 128-row tiles would not
-  if (p.bm == 128 && cdiv(Co, 128) * p.nt < 192 && cdiv(Co, 64) * p.nt >= 192 && p2_bm64_mid()) p.bm = 64;
-  p.lds = ((size_t)3 * (p.bm == 64 ? 2 : 1) * 2 * 4 * p.bm + (size_t)2 * 2 * 4 * p.PXB) * 16;   // [3][G] weight ring + 2 bands
-  if (p.lds > 160 * 1024) return p;
-  p.mt = cdiv(Co, p.bm);
-  p.cpt = Ci / 32;
-  const int tiles = p.mt * p.nt;
-  // mid-sized layers: 128-pixel tiles (conv_fwd_bf16p_kernel) already fill the chip without split-K, 256-pixel
-  // bands would not -- measured faster there
-  if (tiles < 192 && cdiv(Co, 128) * (int)(((long long)B * H * W + 127) / 128) >= 192 && Co > 64) {
-    p.ok = 0;
-    return p;
-  }
-  int splits = 1;
-  static int target = -1;   // blocks aimed at when K is split (ITCV_P2_BLOCKS overrides; diagnostic)
-  if (target < 0) {
-    const char* e = getenv("ITCV_P2_BLOCKS");
-    target = e ? atoi(e) : 256;
-  }
-  if (tiles < 192 && p.cpt >= 2) {
-    splits = target / tiles;
-    if (splits > p.cpt) splits = p.cpt;
-    if (splits < 1) splits = 1;
-  }
-  p.cps = cdiv(p.cpt, splits);
-  p.splits = cdiv(p.cpt, p.cps);
-  p.ok = 1;
-  return p;
-}
-
-template <int LOG2W, int BM, bool UP2>
-static void launch_fwd_p2_cfg(const ConvArgsP2& a, int splits, size_t lds, hipStream_t st) {
-  auto kern = conv_fwd_bf16p2_kernel<LOG2W, BM, UP2>;
-  static size_t attr = 0;
-  if (attr < lds) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr = lds;
-  }
-  dim3 grid(cdiv(a.nt, 8) * 8 * a.mt, splits);
-  launch_timed(kern, grid, dim3(768), lds, st, a);
-}
-template <int LOG2W>
-static void launch_fwd_p2_w(const ConvArgsP2& a, int bm, int up2, int splits, size_t lds, hipStream_t st) {
-  if (bm == 64) {
-    if (up2) launch_fwd_p2_cfg<LOG2W, 64, true>(a, splits, lds, st);
-    else launch_fwd_p2_cfg<LOG2W, 64, false>(a, splits, lds, st);
-  } else {
-    if (up2) launch_fwd_p2_cfg<LOG2W, 128, true>(a, splits, lds, st);
-    else launch_fwd_p2_cfg<LOG2W, 128, false>(a, splits, lds, st);
-  }
 }
 
 struct WgPlanP {
@@ -2743,12 +2364,7 @@ int itcv_conv2d_fwd_bf16p(const void* xplanes, const void* wp, const float* bias
     hipStream_t st = S(stream);
     {
       ProfScope prof(st, 8, log2_exact(W), p2.bm, up2 ? 1 : 0, ns, 2.0 * B * H * W * (double)Co * Ci * KS * KS);
-      switch (log2_exact(W)) {
-        case 3: launch_fwd_p2_w<3>(a, p2.bm, up2, p2.splits, p2.lds, st); break;
-        case 4: launch_fwd_p2_w<4>(a, p2.bm, up2, p2.splits, p2.lds, st); break;
-        case 5: launch_fwd_p2_w<5>(a, p2.bm, up2, p2.splits, p2.lds, st); break;
-        default: launch_fwd_p2_w<6>(a, p2.bm, up2, p2.splits, p2.lds, st); break;
-      }
+      launch_fwd_p2(a, p2, W, up2, st);
     }
     ITCV_CHECK_LAUNCH("itcv_conv2d_fwd_bf16p(band)");
     if (p2.splits > 1) {
@@ -2922,7 +2538,7 @@ int itcv_conv2d_wgrad_bf16s(const float* x, const float* dy, float* dw, int B, i
 // ---- weight gradient on pre-split planes ------------------------------------------------------
 int itcv_conv2d_wgrad_bf16p_supported(int B, int Ci, int H, int W, int Co, int KS) {
   if (KS != 3 || B <= 0 || Ci < 8 || Co < 8 || (Ci & 7) || (Co & 7)) return 0;
-  if (log2_exact(W) < 2 || W > 64 || log2_exact(H) < 0) return 0;
+  if (log2_exact(W) < 2 || W > 256 || log2_exact(H) < 0) return 0;   // W > 64: 64-column segments of a row per step
   const long long px = (long long)B * H * W;
   if (px % 64) return 0;
   if (H * W < 64 && 64 % (H * W)) return 0;
@@ -2942,7 +2558,7 @@ int itcv_conv2d_wgrad_bf16p(const void* xplanes, const void* dyplanes, float* dw
   if (int e = check_dims("itcv_conv2d_wgrad_bf16p", B, Ci, H, W, Co, KS)) return e;
   ITCV_REQUIRE(xplanes && dyplanes && dw, "itcv_conv2d_wgrad_bf16p");
   if (!itcv_conv2d_wgrad_bf16p_supported(B, Ci, H, W, Co, KS))
-    return fail("%s: shape not supported (KS 3, W a power of two in 4..64, H a power of two, C %% 8)", "itcv_conv2d_wgrad_bf16p");
+    return fail("%s: shape not supported (KS 3, W a power of two in 4..256, H a power of two, C %% 8)", "itcv_conv2d_wgrad_bf16p");
   if (up2) ITCV_REQUIRE(H % 2 == 0 && W % 2 == 0, "itcv_conv2d_wgrad_bf16p(up2)");
   const WgPlanP p = plan_wgrad_p(B, Ci, H, W, Co);
   const size_t need = (size_t)p.splits * 9 * Co * Ci * sizeof(float);
@@ -2954,6 +2570,7 @@ int itcv_conv2d_wgrad_bf16p(const void* xplanes, const void* dyplanes, float* dw
   a.tiles_m = p.tiles_m, a.tiles_n = p.tiles_n;
   a.steps = p.steps, a.steps_per_split = p.sps, a.splits = p.splits;
   a.h_shift = log2_exact(H);
+  a.wseg_shift = W > 64 ? log2_exact(W) - 6 : 0;
   a.xplane = (size_t)B * (Ci / 8) * (up2 ? (H / 2) * (W / 2) : H * W);
   a.dyplane = (size_t)B * (Co / 8) * H * W;
 #ifdef ITCV_DIAG

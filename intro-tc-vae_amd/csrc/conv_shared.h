@@ -1,0 +1,85 @@
+// Declarations shared by the conv translation units (conv_igemm.hip, conv_band.hip): vector typedefs, the
+// diagnostic-build switches, the raw-ISA LDS-DMA helpers and the band kernel's host interface.
+#pragma once
+#include <stdlib.h>
+
+#include "common.h"
+
+namespace itcv {
+
+// Diagnostic instrumentation (operand ablation, in-kernel cycle stamps) exists only in -DITCV_DIAG builds
+// (`make diag`, used by tools/abl.sh): in the shipped library the tests below are the constant 0, the branches are
+// compiled out and no environment variable can alter results.
+#ifdef ITCV_DIAG
+#define ITCV_ABL(args, bits) (((args).ablate & (bits)) != 0)
+#define ITCV_DBG(args) ((args).debug != 0)
+static int diag_ablate() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("ITCV_ABLATE");
+    v = e ? atoi(e) : 0;
+  }
+  return v;
+}
+#else
+#define ITCV_ABL(args, bits) (false)
+#define ITCV_DBG(args) (false)
+#endif
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// LDS-DMA of one 16-byte chunk per lane (global -> LDS at lds_base + lane*16), issued as raw ISA: the
+// compiler's own tracking of the builtin puts an `s_waitcnt vmcnt(0)` in front of EVERY later ds_read
+// (it cannot tell the ring slots apart), which serialises the prefetch with the tile being computed.
+// The caller orders the reads by hand (s_waitcnt vmcnt(N) + barrier).
+#pragma clang diagnostic ignored "-Winline-asm"   // m0 is a reserved register: named so the compiler re-materialises it
+__device__ __forceinline__ void lds_dma16(const void* gptr, uint32_t lds_base) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off"
+               :
+               : "s"(__builtin_amdgcn_readfirstlane(lds_base)), "v"(gptr)
+               : "memory", "m0");
+}
+__device__ __forceinline__ uint32_t lds_addr(const void* p) {
+  return (uint32_t)(size_t)(const __attribute__((address_space(3))) void*)p;
+}
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+static inline int log2_exact(int v) {
+  if (v <= 0 || (v & (v - 1))) return -1;
+  int s = 0;
+  while ((1 << s) < v) ++s;
+  return s;
+}
+
+struct ConvArgsP2 {
+  const u32x4* xp;
+  const u32x4* wp;
+  const float* bias;
+  float* y;
+  int B, Ci, H, Co;
+  int Mp, N;
+  int mt, nt;
+  int cpt, cpt_per_split;        // 32-channel groups, and how many of them one split-K slice takes
+  int SR, NSEG, NP, NPC, PXB;    // band geometry: segment rows, segments, halo pixels, 64-chunk pieces, LDS row stride
+  int h_shift;
+  size_t slab_stride, plane_stride;
+#ifdef ITCV_DIAG
+  int debug;   // diagnostic only (ITCV_ABLATE & 64): block 0 / 100 report main-loop shader cycles and 100 MHz ticks in y[0..3]
+#endif
+};
+
+struct FwdPlanP2 {
+  int ok, bm, mt, nt, cpt, splits, cps, SR, NSEG, NP, NPC, PXB;
+  size_t lds;
+};
+
+// conv_band.hip
+FwdPlanP2 plan_fwd_p2(int B, int Ci, int H, int W, int Co, int KS, int ns);
+void launch_fwd_p2(const ConvArgsP2& a, const FwdPlanP2& p, int W, int up2, hipStream_t st);
+
+}  // namespace itcv

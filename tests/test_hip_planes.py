@@ -79,6 +79,8 @@ def test_planes_conv_equals_gather_conv(HF, mode, case):
 WGRAD_CASES = [  # B, Ci, H, W, Co, up2
     (2, 64, 16, 16, 64, False), (4, 128, 4, 4, 256, False), (2, 32, 32, 32, 48, False), (1, 64, 64, 64, 64, False),
     (2, 128, 16, 16, 64, True), (2, 512, 8, 8, 256, False), (8, 24, 8, 8, 136, False),
+    # images wider than the 64-pixel band: one 64-column segment of a row per step (128x128 / 256x256 configurations)
+    (1, 64, 8, 128, 64, False), (2, 32, 4, 256, 128, False), (1, 64, 16, 128, 32, True), (1, 16, 8, 256, 64, True),
 ]
 
 
