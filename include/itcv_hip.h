@@ -246,21 +246,25 @@ int itcv_kl_rows_bwd(const float* g, const float* logvar, const float* mu, float
  *   flags: ITCV_TC_*   variance source, density flavour and sampler
  * Outputs: prodm[Bl] = sum_l logsumexp_i(logW[j,i] + lp[j,i,l]),
  *          logqz[Bl] = logsumexp_i(logW[j,i] + sum_l lp[j,i,l]),
- *          lse[Bl][D]  (saved per-dimension logsumexp, needed by the backward). */
+ *          lse[Bl][D]      (saved per-dimension logsumexp, needed by the backward),
+ *          sjoint[Bl][Bt]  (the joint terms logW[j,i] + sum_l lp[j,i,l] -- without logW for the weighted sampler --
+ *                           saved for the backward, which does not recompute the forward).
+ * Workspace: itcv_tc_fwd_workspace (per-chunk logsumexp partials). */
 #define ITCV_TC_VAR_FROM_ROW 0x1 /* ops.py:81 logvar.unsqueeze(1): variance of sample row j (live path) */
 #define ITCV_TC_EPS_DENSITY 0x2  /* ops.py:15-21 density (var clamp 1e-4, straight-through) else ops.py:24-29 */
 #define ITCV_TC_WEIGHTED 0x4     /* ops.py:92-101 MWS; default ops.py:104-115 MSS */
 #define ITCV_TC_LIVE (ITCV_TC_VAR_FROM_ROW | ITCV_TC_EPS_DENSITY)
+size_t itcv_tc_fwd_workspace(int Bl, int Bt, int D);
 int itcv_tc_fwd(const float* z, const float* mu_all, const float* logvar, float* prodm, float* logqz,
-                float* lse, int Bl, int Bt, int row_offset, int D, int64_t dataset_size, int flags,
-                void* stream);
+                float* lse, float* sjoint, int Bl, int Bt, int row_offset, int D, int64_t dataset_size, int flags,
+                void* ws, size_t ws_bytes, void* stream);
 /* gradient of sum_j g[j] * (logqz[j] - prodm[j]) for the live path (flags == ITCV_TC_LIVE):
  * dz[Bl][D], dlogvar[Bl][D] (rows) and dmu_all[Bt][D] (columns; partial over this rank's rows). */
 size_t itcv_tc_bwd_workspace(int Bl, int Bt);
 int itcv_tc_bwd(const float* g, const float* z, const float* mu_all, const float* logvar,
-                const float* logqz, const float* lse, float* dz, float* dmu_all, float* dlogvar, int Bl,
-                int Bt, int row_offset, int D, int64_t dataset_size, int flags, void* ws, size_t ws_bytes,
-                void* stream);
+                const float* logqz, const float* lse, const float* sjoint, float* dz, float* dmu_all,
+                float* dlogvar, int Bl, int Bt, int row_offset, int D, int64_t dataset_size, int flags, void* ws,
+                size_t ws_bytes, void* stream);
 /* solvers/tc.py:104-121: per-sample log q(z|x) (ops.py:24-29 density, own mu/logvar) and log p(z) */
 int itcv_diag_logdensity_rows(const float* z, const float* mu, const float* logvar, float* logq_cx,
                               float* logpz, int B, int D, void* stream);

@@ -2,10 +2,10 @@
 // O(B^2 D) pairwise Gaussian log-density + minibatch stratified / weighted sampling estimator.
 // Replaces /root/reference/ops.py:15-29,32-49,52-115,136-185 and solvers/tc.py:104-121.
 //
-// The [B,B,D] log-density tensor of the reference is never materialised: one workgroup owns
-// one sample row j, lanes run over the latent dimension l (coalesced reads of mu[i][:]), the
-// per-(j,l) logsumexp over i lives in registers and the per-(j,i) sum over l is a wavefront
-// reduction accumulated in LDS.  VALU/transcendental bound (exp/log per element), not a GEMM:
+// The [B,B,D] log-density tensor of the reference is never materialised: a workgroup owns one
+// sample row j and a chunk of columns i, lanes run over the latent dimension l (coalesced reads of
+// mu[i][:]), the per-(j,l) logsumexp over i is assembled from per-chunk partials and the per-(j,i)
+// sum over l is one wavefront reduction.  VALU/transcendental bound (one exp per element), not a GEMM:
 // the clamp(min=-50) sits inside the sum over l and the per-dimension logsumexp needs every
 // element, so the contraction cannot be moved to the matrix cores without changing results.
 #include <math.h>
@@ -18,7 +18,6 @@ constexpr float kHalfLog2Pi = 0.9189385332046727f;  // 0.5*log(2*pi)
 constexpr float kLog2Pi = 1.8378770664093453f;
 constexpr float kVarEps = 1e-4f;   // ops.py:18
 constexpr float kFloor = -50.f;    // ops.py:21,29
-constexpr int kTcThreads = 256;
 
 struct TcConst {
   float lw_n, lw_s, lw_m;  // log(1/N), log((N-M)/(N M)), log(1/M)        (ops.py:42-49)
@@ -43,109 +42,147 @@ __device__ __forceinline__ float logdens(float d, float lv) {
   return -0.5f * (d * d * expf(-lv) + lv + kLog2Pi);
 }
 
-// One block per local row j.  dynamic LDS: spart[nwaves][Bt]
-// The estimator kernels walk the B_total rows of mu serially per latent column; straight from global memory every
-// step of that walk is an exposed L2 round trip (~0.7 us: 47 us for a 64 x 128 problem).  The rows are therefore
-// staged through LDS tc_chunk(D) (<= 32) at a time (coalesced, once per pass); the arithmetic and its order are unchanged.
-constexpr int kTcChunkMax = 32;
-__host__ __device__ inline int tc_chunk(int D) {   // rows staged per pass: <= 32 and <= 32 KB per array
-  const int r = 8192 / (D > 0 ? D : 1);
-  return r < 1 ? 1 : (r > kTcChunkMax ? kTcChunkMax : r);
-}
-__device__ __forceinline__ void tc_stage_rows(float* dst, const float* __restrict__ src, int row0, int rows, int D) {
-  const int n = rows * D;   // rows are contiguous in memory: one flat copy
-  const float* s0 = src + (size_t)row0 * D;
-  for (int i = threadIdx.x; i < n; i += kTcThreads) dst[i] = s0[i];
+// ---- estimator kernels ------------------------------------------------------------------------------------
+// Work decomposition (round 2): the first version ran one 256-thread block per sample row with the lanes over the
+// latent dimension -- 64 blocks on 256 CUs, half of each block idle at D = 128, two passes of exp/log/divide per
+// element: 43 us for a 64 x 64 x 128 problem and ~8x that for the 8-GPU configuration's 64 x 512 rows.  Now
+//   * the grid is (row j) x (chunk of kTcIC columns i): >= 256 blocks at every size of interest;
+//   * inside a block the four waves take different columns i and the lanes of a wave run over l (D/64 values per
+//     lane), so sum_l lp[j,i,l] is ONE wave reduction owned by one wave and every lane is busy;
+//   * the per-element transcendental work is hoisted: the density is lp = -0.5*(A + d*d*Bv) - C with
+//     A = log(vhat), Bv = 1/vhat (ops.py:15-21) or A = logvar, Bv = exp(-logvar) (ops.py:24-29) computed once per
+//     (variance row, l); what remains per element is one exp for the logsumexp;
+//   * the logsumexp over i is assembled from per-chunk (max, sum exp) partials by a short second kernel, which also
+//     finishes log q(z_j) from the joint terms S[j,i] = logW[j,i] + sum_l lp[j,i,l].  S is an OUTPUT (`sjoint`): the
+//     backward reads it instead of recomputing the forward.
+// Orders of summation are fixed (no atomics): results are bitwise reproducible.
+constexpr int kTcIC = 16;                 // columns i per block: four per wave
+constexpr int kTcRW = kTcIC / 4;
+constexpr int kTcDLMax = 8;               // D <= 512
+
+__host__ __device__ inline int tc_chunks(int Bt) { return (Bt + kTcIC - 1) / kTcIC; }
+
+// A, Bv of the density for one (variance row, l)
+template <bool EPS>
+__device__ __forceinline__ void dens_coef(float lv, float& A, float& Bv) {
+  if (EPS) {
+    const float vh = fmaxf(expf(lv), kVarEps);
+    A = logf(vh), Bv = 1.f / vh;
+  } else {
+    A = lv, Bv = expf(-lv);
+  }
 }
 
-template <bool VROW, bool EPS, bool MWS>
-__global__ __launch_bounds__(kTcThreads) void tc_fwd_kernel(const float* __restrict__ z,
-                                                            const float* __restrict__ mu_all,
-                                                            const float* __restrict__ logvar,
-                                                            float* __restrict__ prodm, float* __restrict__ logqz,
-                                                            float* __restrict__ lse, int Bt, int row_offset, int D,
-                                                            TcConst c) {
-  const int kTcChunk = tc_chunk(D);
-  extern __shared__ __attribute__((aligned(16))) float spart[];
-  __shared__ float red[kTcThreads / 64];
-  const int j = blockIdx.x, jg = row_offset + j;
+template <int DL, bool VROW, bool EPS, bool MWS>
+__global__ __launch_bounds__(256) void tc_fwd_part_kernel(const float* __restrict__ z, const float* __restrict__ mu_all,
+                                                          const float* __restrict__ logvar, float* __restrict__ pmax,
+                                                          float* __restrict__ psum, float* __restrict__ sjoint, int Bt,
+                                                          int row_offset, int D, int nch, TcConst c) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  float* mu_s = sm;                                   // [kTcIC][D]
+  float* A_s = mu_s + kTcIC * D;                      // [kTcIC][D]  (!VROW only)
+  float* B_s = A_s + (VROW ? 0 : kTcIC * D);          // [kTcIC][D]  (!VROW only)
+  float* cm = B_s + (VROW ? 0 : kTcIC * D);           // [4][D] per-wave running max
+  float* cs = cm + 4 * D;                             // [4][D] per-wave sum of exp
+  const int j = blockIdx.x, ch = blockIdx.y, jg = row_offset + j;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  constexpr int NW = kTcThreads / 64;
-  float* mu_s = spart + NW * Bt;                 // [kTcChunk][D]
-  float* lv_s = mu_s + kTcChunk * D;             // [kTcChunk][D], only when the variance comes from row i
-  for (int i = tid; i < NW * Bt; i += kTcThreads) spart[i] = 0.f;
-  __syncthreads();
-
-  float prod_acc = 0.f;  // this thread's share of sum_l logsumexp_i
-  for (int l0 = 0; l0 < D; l0 += kTcThreads) {
-    const int l = l0 + tid;
-    const bool act = l < D;
-    const float zj = act ? z[(size_t)j * D + l] : 0.f;
-    const float lvj = (act && VROW) ? logvar[(size_t)j * D + l] : 0.f;
-    // pass 1: running max over i of (logW + lp); row sums S[j,i] via wave reductions
-    float mx = -INFINITY;
-    for (int i0 = 0; i0 < Bt; i0 += kTcChunk) {
-      const int rows = min(kTcChunk, Bt - i0);
-      __syncthreads();
-      tc_stage_rows(mu_s, mu_all, i0, rows, D);
-      if (!VROW) tc_stage_rows(lv_s, logvar, i0, rows, D);
-      __syncthreads();
-      for (int ii = 0; ii < rows; ++ii) {
-        const int i = i0 + ii;
-        float lp = 0.f;
-        if (act) {
-          const float lv = VROW ? lvj : lv_s[ii * D + l];
-          lp = fmaxf(logdens<EPS>(zj - mu_s[ii * D + l], lv), kFloor);
-          const float v = MWS ? lp : lp + log_iw(c, jg, i);
-          mx = fmaxf(mx, v);
-        }
-        const float s = wave_sum(lp);
-        if (lane == 0) spart[wid * Bt + i] += s;
-      }
-    }
-    // pass 2: sum of exp(v - max)
-    float se = 0.f;
-    for (int i0 = 0; i0 < Bt; i0 += kTcChunk) {
-      const int rows = min(kTcChunk, Bt - i0);
-      __syncthreads();
-      tc_stage_rows(mu_s, mu_all, i0, rows, D);
-      if (!VROW) tc_stage_rows(lv_s, logvar, i0, rows, D);
-      __syncthreads();
-      if (act) {
-        for (int ii = 0; ii < rows; ++ii) {
-          const int i = i0 + ii;
-          const float lv = VROW ? lvj : lv_s[ii * D + l];
-          const float lp = fmaxf(logdens<EPS>(zj - mu_s[ii * D + l], lv), kFloor);
-          const float v = MWS ? lp : lp + log_iw(c, jg, i);
-          se += expf(v - mx);
-        }
-      }
-    }
-    if (act) {
-      float r = mx + logf(se);
-      lse[(size_t)j * D + l] = r;
-      if (MWS) r -= c.log_bn;
-      prod_acc += r;
-    }
+  const int i0 = ch * kTcIC, rows = min(kTcIC, Bt - i0);
+  for (int e = tid; e < rows * D; e += 256) {
+    mu_s[e] = mu_all[(size_t)i0 * D + e];
+    if (!VROW) dens_coef<EPS>(logvar[(size_t)i0 * D + e], A_s[e], B_s[e]);
   }
-  __syncthreads();
-  // log q(z_j) = logsumexp_i(logW + sum_l lp)
-  float mx = -INFINITY;
-  for (int i = tid; i < Bt; i += kTcThreads) {
-    float s = 0.f;
+  float zj[DL], Aj[DL], Bj[DL];
 #pragma unroll
-    for (int w = 0; w < NW; ++w) s += spart[w * Bt + i];
-    if (!MWS) s += log_iw(c, jg, i);
-    spart[i] = s;  // wave 0's slot doubles as the combined row (each i touched by one thread)
-    mx = fmaxf(mx, s);
+  for (int k = 0; k < DL; ++k) {
+    const int l = lane + 64 * k;
+    zj[k] = 0.f, Aj[k] = 0.f, Bj[k] = 0.f;
+    if (l < D) {
+      zj[k] = z[(size_t)j * D + l];
+      if (VROW) dens_coef<EPS>(logvar[(size_t)j * D + l], Aj[k], Bj[k]);
+    }
   }
+  __syncthreads();
+  float v[kTcRW][DL];
+#pragma unroll
+  for (int r = 0; r < kTcRW; ++r) {
+    const int ii = wid + 4 * r;                        // wave-uniform
+    const bool have = ii < rows;
+    const float liw = (have && !MWS) ? log_iw(c, jg, i0 + ii) : 0.f;
+    float part = 0.f;
+#pragma unroll
+    for (int k = 0; k < DL; ++k) {
+      const int l = lane + 64 * k;
+      v[r][k] = -INFINITY;
+      if (have && l < D) {
+        const float d = zj[k] - mu_s[ii * D + l];
+        const float A = VROW ? Aj[k] : A_s[ii * D + l], Bv = VROW ? Bj[k] : B_s[ii * D + l];
+        const float lp = fmaxf(-0.5f * (A + d * d * Bv) - kHalfLog2Pi, kFloor);
+        part += lp;
+        v[r][k] = lp + liw;
+      }
+    }
+    if (have) {
+      part = wave_sum(part);
+      if (lane == 0) sjoint[(size_t)j * Bt + i0 + ii] = part + liw;
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < DL; ++k) {
+    const int l = lane + 64 * k;
+    float m = v[0][k];
+#pragma unroll
+    for (int r = 1; r < kTcRW; ++r) m = fmaxf(m, v[r][k]);
+    float se = 0.f;
+    if (m > -INFINITY) {
+#pragma unroll
+      for (int r = 0; r < kTcRW; ++r) se += expf(v[r][k] - m);     // exp(-inf) = 0 for the rows this wave does not have
+    }
+    if (l < D) cm[wid * D + l] = m, cs[wid * D + l] = se;
+  }
+  __syncthreads();
+  for (int l = tid; l < D; l += 256) {
+    float m = fmaxf(fmaxf(cm[l], cm[D + l]), fmaxf(cm[2 * D + l], cm[3 * D + l]));
+    float se = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      const float mw = cm[w * D + l];
+      if (mw > -INFINITY) se += cs[w * D + l] * expf(mw - m);
+    }
+    pmax[((size_t)j * nch + ch) * D + l] = m;
+    psum[((size_t)j * nch + ch) * D + l] = se;
+  }
+}
+
+// stage 2: block per row j -- lse[j][l], prodm[j], logqz[j]
+template <bool MWS>
+__global__ __launch_bounds__(256) void tc_fwd_finish_kernel(const float* __restrict__ pmax, const float* __restrict__ psum,
+                                                            const float* __restrict__ sjoint, float* __restrict__ prodm,
+                                                            float* __restrict__ logqz, float* __restrict__ lse, int Bt, int D,
+                                                            int nch, TcConst c) {
+  __shared__ float red[4];
+  const int j = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  float prod_acc = 0.f;
+  for (int l = tid; l < D; l += 256) {
+    const float* pm = pmax + (size_t)j * nch * D + l;
+    const float* ps = psum + (size_t)j * nch * D + l;
+    float m = -INFINITY;
+    for (int k = 0; k < nch; ++k) m = fmaxf(m, pm[(size_t)k * D]);
+    float se = 0.f;
+    for (int k = 0; k < nch; ++k) se += ps[(size_t)k * D] * expf(pm[(size_t)k * D] - m);
+    float r = m + logf(se);
+    lse[(size_t)j * D + l] = r;
+    if (MWS) r -= c.log_bn;
+    prod_acc += r;
+  }
+  float mx = -INFINITY;
+  for (int i = tid; i < Bt; i += 256) mx = fmaxf(mx, sjoint[(size_t)j * Bt + i]);
   mx = wave_max(mx);
   if (lane == 0) red[wid] = mx;
   __syncthreads();
   mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
   __syncthreads();
   float se = 0.f;
-  for (int i = tid; i < Bt; i += kTcThreads) se += expf(spart[i] - mx);
+  for (int i = tid; i < Bt; i += 256) se += expf(sjoint[(size_t)j * Bt + i] - mx);
   se = block_sum(se, red);
   const float pm = block_sum(prod_acc, red);
   if (tid == 0) {
@@ -155,129 +192,72 @@ __global__ __launch_bounds__(kTcThreads) void tc_fwd_kernel(const float* __restr
 }
 
 // ---- backward of sum_j g[j]*(logqz[j]-prodm[j]), live path (VROW, EPS, MSS) ------------------
-// Row kernel: block per row j.  Writes wq[j][i] = g_j * softmax_i(logW + S[j,:])[i] to scratch and
-// the row gradients dz[j][:], dlogvar[j][:].
-__global__ __launch_bounds__(kTcThreads) void tc_bwd_rows_kernel(
+//   G[j,i,l] = [lp >= -50] * (wq[j,i] - g_j * exp(lp + logW[j,i] - lse[j,l])),   wq[j,i] = g_j * exp(S[j,i] - logqz[j])
+//   dz[j,l] = -sum_i G d/vhat_j,  dlogvar[j,l] = -var_j * sum_i G * 0.5*(1/vhat_j - (d/vhat_j)^2)   (straight-through clamp)
+//   dmu[i,l] = sum_j G d/vhat_j
+// Row kernel: block (j, 64-wide slice of l); the four waves split the columns i; also writes wq for the column kernel.
+__global__ __launch_bounds__(256) void tc_bwd_rows_kernel(
     const float* __restrict__ g, const float* __restrict__ z, const float* __restrict__ mu_all,
     const float* __restrict__ logvar, const float* __restrict__ logqz, const float* __restrict__ lse,
-    float* __restrict__ wq, float* __restrict__ dz, float* __restrict__ dlogvar, int Bt, int row_offset, int D,
-    TcConst c) {
-  const int kTcChunk = tc_chunk(D);
-  extern __shared__ __attribute__((aligned(16))) float spart[];
-  const int j = blockIdx.x, jg = row_offset + j;
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  constexpr int NW = kTcThreads / 64;
-  float* mu_s = spart + NW * Bt;                 // [kTcChunk][D]
-  for (int i = tid; i < NW * Bt; i += kTcThreads) spart[i] = 0.f;
-  __syncthreads();
-  // S[j,i] exactly as in the forward
-  for (int l0 = 0; l0 < D; l0 += kTcThreads) {
-    const int l = l0 + tid;
-    const bool act = l < D;
-    const float zj = act ? z[(size_t)j * D + l] : 0.f;
-    const float lvj = act ? logvar[(size_t)j * D + l] : 0.f;
-    for (int i0 = 0; i0 < Bt; i0 += kTcChunk) {
-      const int rows = min(kTcChunk, Bt - i0);
-      __syncthreads();
-      tc_stage_rows(mu_s, mu_all, i0, rows, D);
-      __syncthreads();
-      for (int ii = 0; ii < rows; ++ii) {
-        float lp = 0.f;
-        if (act) lp = fmaxf(logdens<true>(zj - mu_s[ii * D + l], lvj), kFloor);
-        const float s = wave_sum(lp);
-        if (lane == 0) spart[wid * Bt + i0 + ii] += s;
-      }
-    }
-  }
-  __syncthreads();
+    const float* __restrict__ sjoint, float* __restrict__ wq, float* __restrict__ dz, float* __restrict__ dlogvar, int Bt,
+    int row_offset, int D, TcConst c) {
+  __shared__ float raz[4][64], rav[4][64];
+  const int j = blockIdx.x, jg = row_offset + j, l = blockIdx.y * 64 + (threadIdx.x & 63);
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const bool act = l < D;
   const float gj = g[j], lq = logqz[j];
-  for (int i = tid; i < Bt; i += kTcThreads) {
-    float s = 0.f;
-#pragma unroll
-    for (int w = 0; w < NW; ++w) s += spart[w * Bt + i];
-    const float q = gj * expf(s + log_iw(c, jg, i) - lq);
-    spart[i] = q;
-    wq[(size_t)j * Bt + i] = q;
-  }
-  __syncthreads();
-  for (int l0 = 0; l0 < D; l0 += kTcThreads) {
-    const int l = l0 + tid;
-    const bool act = l < D;
-    const float zj = act ? z[(size_t)j * D + l] : 0.f, lvj = act ? logvar[(size_t)j * D + l] : 0.f;
-    const float var = expf(lvj), vh = fmaxf(var, kVarEps), lvh = logf(vh);
-    const float ls = act ? lse[(size_t)j * D + l] : 0.f;
-    float az = 0.f, av = 0.f;
-    for (int i0 = 0; i0 < Bt; i0 += kTcChunk) {
-      const int rows = min(kTcChunk, Bt - i0);
-      __syncthreads();
-      tc_stage_rows(mu_s, mu_all, i0, rows, D);
-      __syncthreads();
-      if (act) {
-        for (int ii = 0; ii < rows; ++ii) {
-          const int i = i0 + ii;
-          const float d = zj - mu_s[ii * D + l];
-          const float lp = -(0.5f * (lvh + d * d / vh) + kHalfLog2Pi);
-          if (lp >= kFloor) {  // clamp(min=-50) passes the gradient where lp >= -50
-            const float G = spart[i] - gj * expf(lp + log_iw(c, jg, i) - ls);
-            const float dv = d / vh;
-            az -= G * dv;
-            // d lp / d var at the clamped value, times d var / d logvar of the UNCLAMPED variance
-            av -= G * 0.5f * (1.f / vh - dv * dv);
-          }
-        }
+  const float zj = act ? z[(size_t)j * D + l] : 0.f, lvj = act ? logvar[(size_t)j * D + l] : 0.f;
+  const float var = expf(lvj), vh = fmaxf(var, kVarEps), lvh = logf(vh), ivh = 1.f / vh;
+  const float ls = act ? lse[(size_t)j * D + l] : 0.f;
+  float az = 0.f, av = 0.f;
+#pragma unroll 4
+  for (int i = wid; i < Bt; i += 4) {                  // wave-uniform i: sjoint / log_iw are scalar work
+    const float liw = log_iw(c, jg, i);
+    const float q = gj * expf(sjoint[(size_t)j * Bt + i] - lq);
+    if (blockIdx.y == 0 && lane == 0) wq[(size_t)j * Bt + i] = q;
+    if (act) {
+      const float d = zj - mu_all[(size_t)i * D + l];
+      const float lp = -(0.5f * (lvh + d * d * ivh) + kHalfLog2Pi);
+      if (lp >= kFloor) {                              // clamp(min=-50) passes the gradient where lp >= -50
+        const float G = q - gj * expf(lp + liw - ls);
+        const float dv = d * ivh;
+        az -= G * dv;
+        av -= G * 0.5f * (ivh - dv * dv);              // d lp / d var at the clamped value (straight-through)
       }
     }
-    if (act) {
-      dz[(size_t)j * D + l] = az;
-      dlogvar[(size_t)j * D + l] = av * var;
-    }
+  }
+  raz[wid][lane] = az, rav[wid][lane] = av;
+  __syncthreads();
+  if (wid == 0 && act) {
+    dz[(size_t)j * D + l] = (raz[0][lane] + raz[1][lane]) + (raz[2][lane] + raz[3][lane]);
+    dlogvar[(size_t)j * D + l] = ((rav[0][lane] + rav[1][lane]) + (rav[2][lane] + rav[3][lane])) * var;
   }
 }
 
-// Column kernel: block per column i; dmu_all[i][l] = sum_j G[j,i,l] * (z_j - mu_i)/vhat_j
-__global__ __launch_bounds__(kTcThreads) void tc_bwd_cols_kernel(
+// Column kernel: block (i, 64-wide slice of l); the four waves split the rows j.
+__global__ __launch_bounds__(256) void tc_bwd_cols_kernel(
     const float* __restrict__ g, const float* __restrict__ z, const float* __restrict__ mu_all,
     const float* __restrict__ logvar, const float* __restrict__ lse, const float* __restrict__ wq,
     float* __restrict__ dmu_all, int Bl, int Bt, int row_offset, int D, TcConst c) {
-  const int kTcChunk = tc_chunk(D);
-  extern __shared__ __attribute__((aligned(16))) float cs[];   // z, logvar, lse rows [3][kTcChunk][D], then wq, g [2][kTcChunk]
-  float* z_s = cs;
-  float* lv_s = z_s + kTcChunk * D;
-  float* ls_s = lv_s + kTcChunk * D;
-  float* wq_s = ls_s + kTcChunk * D;
-  float* g_s = wq_s + kTcChunk;
-  const int i = blockIdx.x;
-  for (int l0 = 0; l0 < D; l0 += kTcThreads) {
-    const int l = l0 + threadIdx.x;
-    const bool act = l < D;
-    const float mi = act ? mu_all[(size_t)i * D + l] : 0.f;
-    float acc = 0.f;
-    for (int j0 = 0; j0 < Bl; j0 += kTcChunk) {
-      const int rows = min(kTcChunk, Bl - j0);
-      __syncthreads();
-      tc_stage_rows(z_s, z, j0, rows, D);
-      tc_stage_rows(lv_s, logvar, j0, rows, D);
-      tc_stage_rows(ls_s, lse, j0, rows, D);
-      if ((int)threadIdx.x < rows) {
-        wq_s[threadIdx.x] = wq[(size_t)(j0 + threadIdx.x) * Bt + i];
-        g_s[threadIdx.x] = g[j0 + threadIdx.x];
-      }
-      __syncthreads();
-      if (act) {
-        for (int jj = 0; jj < rows; ++jj) {
-          const float lvj = lv_s[jj * D + l];
-          const float vh = fmaxf(expf(lvj), kVarEps);
-          const float d = z_s[jj * D + l] - mi;
-          const float lp = -(0.5f * (logf(vh) + d * d / vh) + kHalfLog2Pi);
-          if (lp >= kFloor) {
-            const float G = wq_s[jj] - g_s[jj] * expf(lp + log_iw(c, row_offset + j0 + jj, i) - ls_s[jj * D + l]);
-            acc += G * d / vh;
-          }
-        }
-      }
+  __shared__ float racc[4][64];
+  const int i = blockIdx.x, l = blockIdx.y * 64 + (threadIdx.x & 63);
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const bool act = l < D;
+  const float mi = act ? mu_all[(size_t)i * D + l] : 0.f;
+  float acc = 0.f;
+#pragma unroll 2
+  for (int j = wid; j < Bl; j += 4) {
+    const float gj = g[j], q = wq[(size_t)j * Bt + i], liw = log_iw(c, row_offset + j, i);
+    if (act) {
+      const float vh = fmaxf(expf(logvar[(size_t)j * D + l]), kVarEps), ivh = 1.f / vh;
+      const float d = z[(size_t)j * D + l] - mi;
+      const float lp = -(0.5f * (logf(vh) + d * d * ivh) + kHalfLog2Pi);
+      if (lp >= kFloor) acc += (q - gj * expf(lp + liw - lse[(size_t)j * D + l])) * d * ivh;
     }
-    if (act) dmu_all[(size_t)i * D + l] = acc;
   }
+  racc[wid][lane] = acc;
+  __syncthreads();
+  if (wid == 0 && act) dmu_all[(size_t)i * D + l] = (racc[0][lane] + racc[1][lane]) + (racc[2][lane] + racc[3][lane]);
 }
 
 // solvers/tc.py:104-109: log q(z_j|x_j) and log p(z_j) with the ops.py:24-29 density
@@ -389,44 +369,67 @@ int itcv_kl_rows_bwd(const float* g, const float* logvar, const float* mu, float
   return 0;
 }
 
+size_t itcv_tc_fwd_workspace(int Bl, int Bt, int D) {
+  return Bl > 0 && Bt > 0 && D > 0 ? (size_t)2 * Bl * tc_chunks(Bt) * D * sizeof(float) : 0;
+}
+
 int itcv_tc_fwd(const float* z, const float* mu_all, const float* logvar, float* prodm, float* logqz, float* lse,
-                int Bl, int Bt, int row_offset, int D, int64_t dataset_size, int flags, void* stream) {
-  ITCV_REQUIRE(z && mu_all && logvar && prodm && logqz && lse && Bl > 0 && D > 0, "itcv_tc_fwd");
+                float* sjoint, int Bl, int Bt, int row_offset, int D, int64_t dataset_size, int flags, void* ws,
+                size_t ws_bytes, void* stream) {
+  ITCV_REQUIRE(z && mu_all && logvar && prodm && logqz && lse && sjoint && Bl > 0 && D > 0, "itcv_tc_fwd");
   ITCV_REQUIRE(row_offset >= 0 && row_offset + Bl <= Bt, "itcv_tc_fwd(rows must lie inside the global batch)");
+  if (D > 64 * kTcDLMax) return fail("%s: latent size %lld > 512 is not supported", "itcv_tc_fwd", D);
   TcConst c;
   if (int e = make_const("itcv_tc_fwd", Bt, dataset_size, &c)) return e;
+  const int nch = tc_chunks(Bt);
+  ITCV_REQUIRE(ws && ws_bytes >= itcv_tc_fwd_workspace(Bl, Bt, D), "itcv_tc_fwd(workspace)");
+  float* pmax = static_cast<float*>(ws);
+  float* psum = pmax + (size_t)Bl * nch * D;
   const bool vrow = flags & ITCV_TC_VAR_FROM_ROW, eps = flags & ITCV_TC_EPS_DENSITY, mws = flags & ITCV_TC_WEIGHTED;
-  const size_t lds = ((size_t)(kTcThreads / 64) * Bt + (size_t)(vrow ? 1 : 2) * tc_chunk(D) * D) * sizeof(float);
-  if (lds > 128 * 1024) return fail("%s: global batch %lld / latent size too large for the LDS row buffers", "itcv_tc_fwd", Bt);
-  dim3 grid(Bl), block(kTcThreads);
+  const size_t lds = ((size_t)(vrow ? 1 : 3) * kTcIC * D + (size_t)8 * D) * sizeof(float);   // <= 112 KB at D = 512
+  const int dl = D <= 64 ? 1 : (D <= 128 ? 2 : (D <= 256 ? 4 : 8));
+  dim3 grid(Bl, nch), block(256);
   hipStream_t st = S(stream);
-#define ITCV_TC_LAUNCH(V, E, W)                                                                              \
-  do {                                                                                                       \
-    if (lds > 64 * 1024)                                                                                     \
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tc_fwd_kernel<V, E, W>),                      \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                       \
-    hipLaunchKernelGGL((tc_fwd_kernel<V, E, W>), grid, block, lds, st, z, mu_all, logvar, prodm, logqz, lse, \
-                       Bt, row_offset, D, c);                                                                \
+#define ITCV_TC_PART(DL, V, E, W)                                                                               \
+  do {                                                                                                          \
+    if (lds > 64 * 1024)                                                                                        \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tc_fwd_part_kernel<DL, V, E, W>),                 \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                          \
+    hipLaunchKernelGGL((tc_fwd_part_kernel<DL, V, E, W>), grid, block, lds, st, z, mu_all, logvar, pmax, psum,   \
+                       sjoint, Bt, row_offset, D, nch, c);                                                      \
   } while (0)
-  if (vrow && eps && !mws) ITCV_TC_LAUNCH(true, true, false);
-  else if (vrow && eps && mws) ITCV_TC_LAUNCH(true, true, true);
-  else if (vrow && !eps && !mws) ITCV_TC_LAUNCH(true, false, false);
-  else if (vrow && !eps && mws) ITCV_TC_LAUNCH(true, false, true);
-  else if (!vrow && eps && !mws) ITCV_TC_LAUNCH(false, true, false);
-  else if (!vrow && eps && mws) ITCV_TC_LAUNCH(false, true, true);
-  else if (!vrow && !eps && !mws) ITCV_TC_LAUNCH(false, false, false);
-  else ITCV_TC_LAUNCH(false, false, true);
-#undef ITCV_TC_LAUNCH
-  ITCV_CHECK_LAUNCH("itcv_tc_fwd");
+#define ITCV_TC_DL(V, E, W)                \
+  do {                                     \
+    if (dl == 1) ITCV_TC_PART(1, V, E, W); \
+    else if (dl == 2) ITCV_TC_PART(2, V, E, W); \
+    else if (dl == 4) ITCV_TC_PART(4, V, E, W); \
+    else ITCV_TC_PART(8, V, E, W);         \
+  } while (0)
+  if (vrow && eps && !mws) ITCV_TC_DL(true, true, false);
+  else if (vrow && eps && mws) ITCV_TC_DL(true, true, true);
+  else if (vrow && !eps && !mws) ITCV_TC_DL(true, false, false);
+  else if (vrow && !eps && mws) ITCV_TC_DL(true, false, true);
+  else if (!vrow && eps && !mws) ITCV_TC_DL(false, true, false);
+  else if (!vrow && eps && mws) ITCV_TC_DL(false, true, true);
+  else if (!vrow && !eps && !mws) ITCV_TC_DL(false, false, false);
+  else ITCV_TC_DL(false, false, true);
+#undef ITCV_TC_DL
+#undef ITCV_TC_PART
+  ITCV_CHECK_LAUNCH("itcv_tc_fwd(partials)");
+  if (mws)
+    hipLaunchKernelGGL(tc_fwd_finish_kernel<true>, dim3(Bl), block, 0, st, pmax, psum, sjoint, prodm, logqz, lse, Bt, D, nch, c);
+  else
+    hipLaunchKernelGGL(tc_fwd_finish_kernel<false>, dim3(Bl), block, 0, st, pmax, psum, sjoint, prodm, logqz, lse, Bt, D, nch, c);
+  ITCV_CHECK_LAUNCH("itcv_tc_fwd(finish)");
   return 0;
 }
 
 size_t itcv_tc_bwd_workspace(int Bl, int Bt) { return Bl > 0 && Bt > 0 ? (size_t)Bl * Bt * sizeof(float) : 0; }
 
 int itcv_tc_bwd(const float* g, const float* z, const float* mu_all, const float* logvar, const float* logqz,
-                const float* lse, float* dz, float* dmu_all, float* dlogvar, int Bl, int Bt, int row_offset, int D,
-                int64_t dataset_size, int flags, void* ws, size_t ws_bytes, void* stream) {
-  ITCV_REQUIRE(g && z && mu_all && logvar && logqz && lse && dz && dmu_all && dlogvar && Bl > 0 && D > 0,
+                const float* lse, const float* sjoint, float* dz, float* dmu_all, float* dlogvar, int Bl, int Bt,
+                int row_offset, int D, int64_t dataset_size, int flags, void* ws, size_t ws_bytes, void* stream) {
+  ITCV_REQUIRE(g && z && mu_all && logvar && logqz && lse && sjoint && dz && dmu_all && dlogvar && Bl > 0 && D > 0,
                "itcv_tc_bwd");
   ITCV_REQUIRE(row_offset >= 0 && row_offset + Bl <= Bt, "itcv_tc_bwd(rows must lie inside the global batch)");
   if (flags != ITCV_TC_LIVE)
@@ -434,23 +437,14 @@ int itcv_tc_bwd(const float* g, const float* z, const float* mu_all, const float
   ITCV_REQUIRE(ws && ws_bytes >= (size_t)Bl * Bt * sizeof(float), "itcv_tc_bwd(workspace)");
   TcConst c;
   if (int e = make_const("itcv_tc_bwd", Bt, dataset_size, &c)) return e;
-  const size_t lds = ((size_t)(kTcThreads / 64) * Bt + (size_t)tc_chunk(D) * D) * sizeof(float);
-  const size_t lds_c = ((size_t)3 * tc_chunk(D) * D + 2 * tc_chunk(D)) * sizeof(float);
-  if (lds > 128 * 1024 || lds_c > 128 * 1024)
-    return fail("%s: global batch %lld / latent size too large for the LDS row buffers", "itcv_tc_bwd", Bt);
-  if (lds > 64 * 1024)
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tc_bwd_rows_kernel),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  if (lds_c > 64 * 1024)
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tc_bwd_cols_kernel),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_c);
   float* wq = static_cast<float*>(ws);
   hipStream_t st = S(stream);
-  hipLaunchKernelGGL(tc_bwd_rows_kernel, dim3(Bl), dim3(kTcThreads), lds, st, g, z, mu_all, logvar, logqz, lse, wq, dz,
+  const int lch = cdiv(D, 64);
+  hipLaunchKernelGGL(tc_bwd_rows_kernel, dim3(Bl, lch), dim3(256), 0, st, g, z, mu_all, logvar, logqz, lse, sjoint, wq, dz,
                      dlogvar, Bt, row_offset, D, c);
   ITCV_CHECK_LAUNCH("itcv_tc_bwd(rows)");
-  hipLaunchKernelGGL(tc_bwd_cols_kernel, dim3(Bt), dim3(kTcThreads), lds_c, st, g, z, mu_all, logvar, lse, wq, dmu_all, Bl,
-                     Bt, row_offset, D, c);
+  hipLaunchKernelGGL(tc_bwd_cols_kernel, dim3(Bt, lch), dim3(256), 0, st, g, z, mu_all, logvar, lse, wq, dmu_all, Bl, Bt,
+                     row_offset, D, c);
   ITCV_CHECK_LAUNCH("itcv_tc_bwd(cols)");
   return 0;
 }

@@ -96,9 +96,10 @@ SIGNATURES = {
     "itcv_reparam_bwd": (i32, [p, p, p, p, p, sz, p]),
     "itcv_kl_rows_fwd": (i32, [p, p, p, i32, i32, p]),
     "itcv_kl_rows_bwd": (i32, [p, p, p, p, p, i32, i32, p]),
-    "itcv_tc_fwd": (i32, [p, p, p, p, p, p, i32, i32, i32, i32, i64, i32, p]),
+    "itcv_tc_fwd_workspace": (sz, [i32, i32, i32]),
+    "itcv_tc_fwd": (i32, [p, p, p, p, p, p, p, i32, i32, i32, i32, i64, i32, p, sz, p]),
     "itcv_tc_bwd_workspace": (sz, [i32, i32]),
-    "itcv_tc_bwd": (i32, [p, p, p, p, p, p, p, p, p, i32, i32, i32, i32, i64, i32, p, sz, p]),
+    "itcv_tc_bwd": (i32, [p, p, p, p, p, p, p, p, p, p, i32, i32, i32, i32, i64, i32, p, sz, p]),
     "itcv_diag_logdensity_rows": (i32, [p, p, p, p, p, i32, i32, p]),
     "itcv_recon_workspace": (sz, [i32, sz]),
     "itcv_recon_rows_fwd": (i32, [p, p, p, i32, sz, i32, p, sz, p]),

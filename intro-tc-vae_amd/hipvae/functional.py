@@ -842,8 +842,9 @@ class KlRowsFn(Function):
         return dlv, dmu
 
 
-def tc_components(z, mu_all, logvar, dataset_size, row_offset=0, flags=abi.TC_LIVE):
-    """(prodm[Bl], logqz[Bl], lse[Bl,D]) of the fused pairwise-density / sampling kernel."""
+def tc_components(z, mu_all, logvar, dataset_size, row_offset=0, flags=abi.TC_LIVE, with_joint=False):
+    """(prodm[Bl], logqz[Bl], lse[Bl,D]) of the fused pairwise-density / sampling kernel (+ the joint terms
+    S[Bl,Bt] the backward reads, with ``with_joint``)."""
     z, mu_all, logvar = _f32c(z), _f32c(mu_all), _f32c(logvar)
     Bl, D = z.shape
     Bt = mu_all.shape[0]
@@ -851,9 +852,12 @@ def tc_components(z, mu_all, logvar, dataset_size, row_offset=0, flags=abi.TC_LI
     prodm = torch.empty((Bl,), dtype=F32, device=dev)
     logqz = torch.empty((Bl,), dtype=F32, device=dev)
     lse = torch.empty((Bl, D), dtype=F32, device=dev)
-    call("itcv_tc_fwd", ptr(z), ptr(mu_all), ptr(logvar), ptr(prodm), ptr(logqz), ptr(lse), Bl, Bt, int(row_offset), D,
-         int(dataset_size), int(flags), stream())
-    return prodm, logqz, lse
+    sjoint = torch.empty((Bl, Bt), dtype=F32, device=dev)
+    nws = lib.itcv_tc_fwd_workspace(Bl, Bt, D)
+    ws = _ws(nws, dev)
+    call("itcv_tc_fwd", ptr(z), ptr(mu_all), ptr(logvar), ptr(prodm), ptr(logqz), ptr(lse), ptr(sjoint), Bl, Bt,
+         int(row_offset), D, int(dataset_size), int(flags), ptr(ws), nws, stream())
+    return (prodm, logqz, lse, sjoint) if with_joint else (prodm, logqz, lse)
 
 
 class TcRowsFn(Function):
@@ -862,15 +866,15 @@ class TcRowsFn(Function):
 
     @staticmethod
     def forward(ctx, z, mu_all, logvar, dataset_size, row_offset):
-        prodm, logqz, lse = tc_components(z, mu_all, logvar, dataset_size, row_offset, abi.TC_LIVE)
-        ctx.save_for_backward(_f32c(z), _f32c(mu_all), _f32c(logvar), logqz, lse)
+        prodm, logqz, lse, sjoint = tc_components(z, mu_all, logvar, dataset_size, row_offset, abi.TC_LIVE, True)
+        ctx.save_for_backward(_f32c(z), _f32c(mu_all), _f32c(logvar), logqz, lse, sjoint)
         ctx.cfg = (int(dataset_size), int(row_offset))
         return logqz - prodm
 
     @staticmethod
     @once_differentiable
     def backward(ctx, g):
-        z, mu_all, logvar, logqz, lse = ctx.saved_tensors
+        z, mu_all, logvar, logqz, lse, sjoint = ctx.saved_tensors
         n, off = ctx.cfg
         Bl, D = z.shape
         Bt = mu_all.shape[0]
@@ -878,8 +882,8 @@ class TcRowsFn(Function):
         dz, dlv, dmu = torch.empty_like(z), torch.empty_like(logvar), torch.empty_like(mu_all)
         nws = lib.itcv_tc_bwd_workspace(Bl, Bt)
         ws = _ws(nws, z.device)
-        call("itcv_tc_bwd", ptr(g), ptr(z), ptr(mu_all), ptr(logvar), ptr(logqz), ptr(lse), ptr(dz), ptr(dmu), ptr(dlv),
-             Bl, Bt, off, D, n, abi.TC_LIVE, ptr(ws), nws, stream())
+        call("itcv_tc_bwd", ptr(g), ptr(z), ptr(mu_all), ptr(logvar), ptr(logqz), ptr(lse), ptr(sjoint), ptr(dz), ptr(dmu),
+             ptr(dlv), Bl, Bt, off, D, n, abi.TC_LIVE, ptr(ws), nws, stream())
         return dz, dmu, dlv, None, None
 
 

@@ -43,7 +43,7 @@ def test_host_side_argument_checks_need_no_gpu():
     # argument validation happens before any launch
     assert abi.lib.itcv_conv2d_fwd(None, None, None, None, 1, 1, 1, 1, 1, 7, 0, None, 0, None) != 0
     assert "kernel size" in abi.last_error()
-    assert abi.lib.itcv_tc_fwd(None, None, None, None, None, None, 4, 4, 0, 8, 100, 3, None) != 0
+    assert abi.lib.itcv_tc_fwd(None, None, None, None, None, None, None, 4, 4, 0, 8, 100, 3, None, 0, None) != 0
     with pytest.raises(RuntimeError):
         abi.call("itcv_adam_step", None, None, None, None, 10, 1e-3, 0.9, 0.999, 1e-8, 1, None)
 
