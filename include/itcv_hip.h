@@ -85,6 +85,14 @@ int itcv_split_planes(const float* x, void* planes, int B, int C, int HW, int ns
 size_t itcv_conv2d_fwd_bf16p_workspace(int B, int Ci, int H, int W, int Co, int KS, int ns);
 int itcv_conv2d_fwd_bf16p(const void* xplanes, const void* wp, const float* bias, float* y, int B, int Ci, int H,
                           int W, int Co, int KS, int up2, int ns, void* ws, size_t ws_bytes, void* stream);
+/* The same with the BatchNorm statistics of the consumer layer (models.py:37: conv -> BatchNorm) fused into the conv
+ * epilogue: tile_stats[(k*Co + c)*T + t], k = 0: sum, k = 1: sum of squares of output channel c over the t-th tile of
+ * 256 consecutive (image, pixel) positions, T = itcv_conv2d_fwd_bf16p_stat_tiles(...) (0 = not available for the shape:
+ * pass NULL).  itcv_bn_train_fwd folds them (fp64) instead of reading the tensor once more. */
+int itcv_conv2d_fwd_bf16p_stat_tiles(int B, int Ci, int H, int W, int Co, int KS, int ns);
+int itcv_conv2d_fwd_bf16p_st(const void* xplanes, const void* wp, const float* bias, float* y, int B, int Ci, int H,
+                             int W, int Co, int KS, int up2, int ns, float* tile_stats, void* ws, size_t ws_bytes,
+                             void* stream);
 /* Weight gradient from the same planes (x: [2][B][Ci/8][Hs][Ws], dy: [2][B][Co/8][H][W]); the pixel
  * reduction runs through the gfx950 transposing LDS read, so no pixel-major copy is needed.  bf16x3
  * only; KS = 3, W a power of two in 4..64, H a power of two, B*H*W % 64 == 0 (see _supported).  Replaces
@@ -210,7 +218,11 @@ int itcv_bn_act_bwd_apply(const float* x, const float* dy, const float* mean, co
 int itcv_bn_train_fwd(const float* x, const float* gamma, const float* beta, const float* skip, float* y, void* planes,
                       int ns, int B, int C, int H, int W, float slope, int pool, float eps, float momentum,
                       float* running_mean, float* running_var, int64_t* num_batches_tracked, float* mean, float* rstd,
-                      void* ws, size_t ws_bytes, size_t plane_stride, void* stream);
+                      void* ws, size_t ws_bytes, size_t plane_stride, const float* tile_stats, int tiles, int tile_pitch,
+                      void* stream);
+/* tile_stats (may be NULL): per-tile sums of x written by the producing conv (itcv_conv2d_fwd_bf16p_st):
+ * sum at tile_stats[c*tile_pitch + t], sum of squares at tile_stats[(C + c)*tile_pitch + t], t < tiles -- the tiles
+ * that make up THIS call's B images; the statistics are then folded from them and x is read once (apply) only. */
 int itcv_bn_train_bwd(const float* x, const float* dy, const float* mean, const float* rstd, const float* gamma,
                       const float* beta, const float* skip, double* dsums, float* dx, float* dskip, void* dx_planes,
                       int ns, float* dgamma, float* dbeta, int accumulate, int B, int C, int H, int W, float slope,

@@ -224,9 +224,36 @@ __global__ __launch_bounds__(768) void conv_fwd_bf16p2_kernel(ConvArgsP2 a) {
     return;
   }
 
-  // ---- epilogue: the tile goes through LDS once so that every global store is a 16-byte-per-lane, 1-KB-per-wave piece
-  // of one channel row (a lane of the 32x32 accumulator holds ONE pixel of 16 channels: stored straight from the
-  // registers that is 32-64 dword stores per lane and the store issue, not the bandwidth, sets the epilogue's length).
+  float* out = a.y + (size_t)sk * a.slab_stride;
+  if (!a.stats) {
+    // ---- epilogue, direct form: every lane stores its accumulator elements (one pixel of 16 channels per 32x32 tile:
+    // 128-byte row pieces per half wave)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int nn = n0 + wn * WTN + j * 32 + l31;
+      if (nn >= a.N) continue;
+      const int b2 = nn / HW, hw2 = nn - b2 * HW;
+      const size_t base = (size_t)b2 * a.Co * HW + hw2;
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+          if (m < a.Co) {
+            float v = acc[i][j][r];
+            if (a.bias) v += a.bias[m];
+            out[base + (size_t)m * HW] = v;
+          }
+        }
+      }
+    }
+    return;
+  }
+  // ---- epilogue, staged form (when the consumer BatchNorm's statistics are wanted from this launch): the tile goes
+  // through LDS once, every global store is a 16-byte-per-lane / 1-KB-per-wave piece of one channel row, and the row's
+  // sum and sum of squares fall out of the same registers.  Measured (64 -> 64 @ 64x64, 128 images): 146 us against 135 us
+  // for the direct form -- more than the 8.6-us statistics pass it replaces saves (that pass reads the tensor out of the
+  // Infinity Cache right behind this kernel), which is why the solvers leave it off (ITCV_FUSE_BN_STATS=1 turns it on).
   // The rings and bands are dead: every wave has passed the slice's last barrier with all LDS-DMA landed.
   constexpr int EP = BN + 4;                                   // floats per staged channel row (1040 B: 16-byte aligned)
   float* stg = reinterpret_cast<float*>(smem);                 // [BM][EP]
@@ -238,7 +265,6 @@ __global__ __launch_bounds__(768) void conv_fwd_bf16p2_kernel(ConvArgsP2 a) {
       for (int r = 0; r < 16; ++r)
         stg[(wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * EP + wn * WTN + j * 32 + l31] = acc[i][j][r];
   __builtin_amdgcn_s_barrier();                                // the eight MFMA waves (the loader waves have ended)
-  float* out = a.y + (size_t)sk * a.slab_stride;
   const int nn = n0 + 4 * lane;                                // this lane's 4 consecutive pixels of every row
   const int b2 = nn / HW, hw2 = nn - b2 * HW;                  // HW % 4 == 0: the four stay inside one image
   const size_t base = (size_t)b2 * a.Co * HW + hw2;
@@ -253,6 +279,280 @@ __global__ __launch_bounds__(768) void conv_fwd_bf16p2_kernel(ConvArgsP2 a) {
       v[0] += bv, v[1] += bv, v[2] += bv, v[3] += bv;
     }
     if (live) *reinterpret_cast<f32x4*>(out + base + (size_t)m * HW) = v;
+    // this tile's sum and sum of squares of channel m (fp32 over 256 values; the per-channel fold over tiles runs in
+    // fp64, norm_act.hip).  Fixed order: reproducible.
+    float s1 = live ? (v[0] + v[1]) + (v[2] + v[3]) : 0.f;
+    float s2 = live ? (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]) : 0.f;
+    s1 = wave_sum(s1), s2 = wave_sum(s2);
+    if (lane == 0) {
+      a.stats[(size_t)m * a.stat_T + tile_n] = s1;
+      a.stats[((size_t)a.Co + m) * a.stat_T + tile_n] = s2;
+    }
+  }
+}
+
+// ---- persistent form of the band kernel -------------------------------------------------------------------
+// conv_fwd_bf16p2_kernel runs one tile per block, one block per CU (its LDS fills the CU), so a CU's timeline is
+// [band + weights arrive | MFMA | stores leave] and all 256 CUs go through those phases together: on the 64-channel
+// layers (K = 576) the matrix cores sit idle about half of the kernel.  Here a block walks a LIST of tiles
+// (tile = blockIdx.x, += gridDim.x) and treats (tile, channel group) as one continuous stream of groups: during the
+// last group of a tile the loader waves already fetch the FIRST band of the next tile into the band buffer that has just
+// become free (and the weight ring simply wraps to the next tile's first taps), and the MFMA waves' result stores of
+// tile t drain while tile t+1 is multiplied.  Barrier structure, counted waits, K order and arithmetic are those of the
+// one-tile kernel (bit-identical results).
+template <int LOG2W, int BM, bool UP2>
+__global__ __launch_bounds__(768) void conv_fwd_bf16p3_kernel(ConvArgsP2 a) {
+  constexpr int W = 1 << LOG2W, WP = W + 2, BN = 256, KC = 4, NS = 2;
+  constexpr int WM = BM / 64, WN = 8 / WM, WTN = BN / WN, TM = 2, TN = WTN / 32;
+  constexpr int ASZ = NS * KC * BM;
+  constexpr int PA = NS * KC * BM / 64 / 4;
+  constexpr int G = BM == 64 ? 2 : 1, NSTG = (9 + G - 1) / G;
+  extern __shared__ u32x4 smem[];
+
+  const int t = threadIdx.x, lane = t & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int sk = blockIdx.y;
+  const int c0 = sk * a.cpt_per_split, c1 = min(a.cpt, c0 + a.cpt_per_split);
+  if (c0 >= c1) return;
+  const int nk = (c1 - c0) * 9;
+  const int H = a.H, HW = H << LOG2W;
+  const int PXB = a.PXB, BSZ = NS * KC * PXB;
+  const uint32_t smem_base = lds_addr(smem);
+  const uint32_t band_base = smem_base + 3u * G * ASZ * 16u;
+  // tile ids of this block: id = blockIdx.x + k * gridDim.x over the padded id space of the one-tile kernel
+  // (id & 7 = XCD slot, so a block keeps its XCD); ids whose N tile lies past the end are skipped -- by every wave alike
+  const int nids = ((a.nt + 7) >> 3) * 8 * a.mt, stride = gridDim.x;
+  auto tile_n_of = [&](int id) { return ((id >> 3) / a.mt) * 8 + (id & 7); };
+  auto tile_m_of = [&](int id) { return (id >> 3) % a.mt; };
+  auto next_tile = [&](int id) {
+    id += stride;
+    while (id < nids && tile_n_of(id) >= a.nt) id += stride;
+    return id;
+  };
+  int tcur = (int)blockIdx.x - stride;
+  tcur = next_tile(tcur);
+  if (tcur >= nids) return;
+
+  if (wid >= 8) {
+    // ------------------------------------------------------------------ loaders
+    const int lw = wid - 8;
+    const int Hs = UP2 ? H / 2 : H, Ws = UP2 ? W / 2 : W, HWs = Hs * Ws;
+    const int C8 = a.Ci >> 3;
+    const u32x4* zero = &g_zero_chunk;
+    const int seg_px = (a.SR + 2) * WP;
+    long long soff[8], soff_n[8];
+    uint32_t vmask = 0, vmask_n = 0;
+    auto band_offsets = [&](int id, long long (&so)[8], uint32_t& vm) {
+      const int R0 = (tile_n_of(id) * BN) >> LOG2W;
+      vm = 0;
+#pragma unroll
+      for (int qq = 0; qq < 8; ++qq) {
+        const int hp = qq * 64 + lane;
+        so[qq] = 0;
+        if (qq < a.NPC && hp < a.NP) {
+          const int seg = hp / seg_px, rem = hp - seg * seg_px, hr = rem / WP, hc = rem - hr * WP;
+          const int grow = R0 + seg * a.SR, b = grow >> a.h_shift, h = (grow & (H - 1)) + hr - 1, wv = hc - 1;
+          if (b < a.B && (unsigned)h < (unsigned)H && (unsigned)wv < (unsigned)W) {
+            vm |= 1u << qq;
+            so[qq] = (long long)b * C8 * HWs + (UP2 ? (h >> 1) * Ws + (wv >> 1) : h * W + wv);
+          }
+        }
+      }
+    };
+    // every wave instruction below is issued by all 64 lanes (never skipped): the counted vmcnt waits rely on it
+    auto issue_band_piece = [&](int cib, int buf, long long so, bool valid, int qq) {
+#pragma unroll
+      for (int pl = 0; pl < NS; ++pl) {
+        const u32x4* src = a.xp + ((size_t)pl * a.plane_stride + (size_t)(cib * KC + lw) * HWs + so);
+        lds_dma16(valid ? src : zero, band_base + (uint32_t)(buf * BSZ + (pl * KC + lw) * PXB + qq * 64) * 16u);
+      }
+    };
+    int m0 = tile_m_of(tcur) * BM, m0_n = m0;      // weight rows of the current / the next tile
+    auto issue_A = [&](int i, int slot, int mrow) {   // weight tile of K-tile i of this slice
+      const int kt = c0 * 9 + i;
+      const u32x4* wt = a.wp + (size_t)kt * NS * KC * a.Mp + mrow + lane;
+      const uint32_t sbase = smem_base + (uint32_t)(slot * ASZ) * 16u;
+#pragma unroll
+      for (int j = 0; j < PA; ++j) {
+        const int piece = j * 4 + lw, mlc = piece % (BM / 64), pk = piece / (BM / 64);
+        lds_dma16(wt + (size_t)pk * a.Mp + mlc * 64, sbase + (uint32_t)(pk * BM + mlc * 64) * 16u);
+      }
+    };
+    // weight tiles of one stage (taps st*G .. of group cib) -> ring slot `slot`.  Past the end of the tile's slice the
+    // ring wraps to the first taps of the NEXT tile (`more`), or -- after the last tile -- fetches the last K-tile again
+    // (same instruction count: the counted waits stay valid)
+    auto issue_stage_A = [&](int cib, int st, int slot, bool more) {
+#pragma unroll
+      for (int u = 0; u < G; ++u)
+        if (st * G + u < 9) {
+          int i = (cib - c0) * 9 + st * G + u, mrow = m0;
+          if (i >= nk) {
+            if (more) i -= nk, mrow = m0_n;
+            else i = nk - 1;
+          }
+          issue_A(i, slot * G + u, mrow);
+        }
+    };
+    auto stage_taps = [](int st) { return (st * G + G <= 9) ? G : 9 - st * G; };
+    band_offsets(tcur, soff, vmask);
+    int tnext = next_tile(tcur);
+    bool more = tnext < nids;
+    if (more) m0_n = tile_m_of(tnext) * BM;
+#pragma unroll
+    for (int qq = 0; qq < 8; ++qq)
+      if (qq < a.NPC) issue_band_piece(c0, 0, soff[qq], (vmask >> qq) & 1u, qq);
+    issue_stage_A(c0, 0, 0, more);
+    issue_stage_A(c0, 1, 1, more);
+    wait_vmcnt<PA * (NSTG > 1 ? ((1 * G + G <= 9) ? G : 9 - G) : 0)>();   // band and stage 0 landed; stage 1 may be in flight
+    __builtin_amdgcn_s_barrier();
+    int buf = 0, slot = 2;
+    while (true) {
+      for (int cib = c0; cib < c1; ++cib) {
+        const bool last_group = cib + 1 == c1;
+        if (last_group && more) band_offsets(tnext, soff_n, vmask_n);    // the next tile's band goes out during this group
+        const bool pre = !last_group || more;                           // is there a following group to prefetch?
+#pragma unroll
+        for (int st = 0; st < NSTG; ++st) {
+          const int st2 = (st + 2) % NSTG, cib2 = cib + (st + 2) / NSTG;
+          issue_stage_A(cib2, st2, slot, more);                 // into the slot stage S-1 has just left
+          if (++slot == 3) slot = 0;
+          // the following group's band, one piece (x 2 planes) per tap of this stage
+          int nb = 0;
+#pragma unroll
+          for (int u = 0; u < G; ++u) {
+            const int tap = st * G + u;
+            if (tap < 8 && tap < a.NPC && pre) {
+              if (last_group) issue_band_piece(c0, buf ^ 1, soff_n[tap < 8 ? tap : 0], (vmask_n >> tap) & 1u, tap);
+              else issue_band_piece(cib + 1, buf ^ 1, soff[tap < 8 ? tap : 0], (vmask >> tap) & 1u, tap);
+              ++nb;
+            }
+          }
+          // stage S+1's weights (and everything older) have landed: only this iteration's loads may be in flight
+          const int na = stage_taps(st2);
+          if (na == G) {
+            if (nb == 0) wait_vmcnt<PA * G>();
+            else if (nb == 1) wait_vmcnt<PA * G + NS>();
+            else wait_vmcnt<PA * G + 2 * NS>();
+          } else {
+            if (nb == 0) wait_vmcnt<PA*(9 % G ? 9 % G : G)>();
+            else if (nb == 1) wait_vmcnt<PA*(9 % G ? 9 % G : G) + NS>();
+            else wait_vmcnt<PA*(9 % G ? 9 % G : G) + 2 * NS>();
+          }
+          __builtin_amdgcn_s_barrier();
+        }
+        buf ^= 1;
+      }
+      if (!more) break;
+      tcur = tnext;
+      m0 = m0_n;
+#pragma unroll
+      for (int qq = 0; qq < 8; ++qq) soff[qq] = soff_n[qq];
+      vmask = vmask_n;
+      tnext = next_tile(tcur);
+      more = tnext < nids;
+      if (more) m0_n = tile_m_of(tnext) * BM;
+    }
+    return;
+  }
+
+  // -------------------------------------------------------------------- MFMA waves
+  const int wm = wid / WN, wn = wid % WN, l31 = lane & 31, half = lane >> 5;
+  uint32_t hoff[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int nl = wn * WTN + j * 32 + l31, R = nl >> LOG2W, w = nl & (W - 1);
+    const int seg = R / a.SR, rr = R - seg * a.SR;
+    hoff[j] = (uint32_t)((seg * (a.SR + 2) + rr + 1) * WP + w + 1) * 16u;
+  }
+  const uint32_t aoff = (uint32_t)(wm * 64 + l31) * 16u;
+  __builtin_amdgcn_s_barrier();
+  int buf = 0, slot = 0;
+  while (tcur < nids) {
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    for (int cib = c0; cib < c1; ++cib) {
+      const uint32_t bb = band_base + (uint32_t)(buf * BSZ) * 16u;
+#pragma unroll
+      for (int st = 0; st < NSTG; ++st) {
+#pragma unroll
+        for (int u = 0; u < G; ++u) {
+          const int tap = st * G + u;
+          if (tap >= 9) continue;
+          const int tapoff = ((tap / 3 - 1) * WP + (tap % 3 - 1)) * 16;
+          const uint32_t ab = smem_base + (uint32_t)((slot * G + u) * ASZ) * 16u + aoff;
+          bf16x8 af[2][NS][TM], bfr[2][NS][TN];
+#pragma unroll
+          for (int ks = 0; ks < 2; ++ks) {
+            const int kc = ks * 2 + half;
+#pragma unroll
+            for (int pp = 0; pp < NS; ++pp) {
+#pragma unroll
+              for (int i = 0; i < TM; ++i)
+                af[ks][pp][i] = __builtin_bit_cast(
+                    bf16x8, *(const __attribute__((address_space(3))) u32x4*)(size_t)(ab + (uint32_t)(((pp * KC + kc) * BM + i * 32) * 16)));
+#pragma unroll
+              for (int j = 0; j < TN; ++j)
+                bfr[ks][pp][j] = __builtin_bit_cast(
+                    bf16x8, *(const __attribute__((address_space(3))) u32x4*)(size_t)(bb + (uint32_t)((pp * KC + kc) * PXB) * 16u + hoff[j] + tapoff));
+            }
+          }
+#pragma unroll
+          for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+              for (int j = 0; j < TN; ++j) {
+                f32x16 c = acc[i][j];
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks][0][i], bfr[ks][1][j], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks][1][i], bfr[ks][0][j], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks][0][i], bfr[ks][0][j], c, 0, 0, 0);
+                acc[i][j] = c;
+              }
+          {
+            constexpr int RD = NS * (TM + TN), MF = TM * TN * 3;   // LDS reads / MFMAs per k-step
+            __builtin_amdgcn_sched_group_barrier(0x100, RD, 0);
+#pragma unroll
+            for (int r = 0; r < RD; ++r) {
+              __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+              __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, 2 * MF - RD, 0);
+          }
+        }
+        if (++slot == 3) slot = 0;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+      }
+      buf ^= 1;
+    }
+    // result of this tile: plain stores, left to drain under the next tile's MFMAs
+    const int m0 = tile_m_of(tcur) * BM, n0 = tile_n_of(tcur) * BN;
+    float* out = a.y + (size_t)sk * a.slab_stride;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int nn = n0 + wn * WTN + j * 32 + l31;
+      if (nn >= a.N) continue;
+      const int b2 = nn / HW, hw2 = nn - b2 * HW;
+      const size_t base = (size_t)b2 * a.Co * HW + hw2;
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+          if (m < a.Co) {
+            float v = acc[i][j][r];
+            if (a.bias) v += a.bias[m];
+            out[base + (size_t)m * HW] = v;
+          }
+        }
+      }
+    }
+    tcur = next_tile(tcur);
   }
 }
 
@@ -316,6 +616,15 @@ FwdPlanP2 plan_fwd_p2(int B, int Ci, int H, int W, int Co, int KS, int ns) {
   return p;
 }
 
+static int band_persistent_blocks() {   // ITCV_BAND_PERSIST=0: one tile per block always (diagnostic); else the block count
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("ITCV_BAND_PERSIST");
+    v = e ? atoi(e) : 256;
+  }
+  return v;
+}
+
 template <int LOG2W, int BM, bool UP2>
 static void launch_fwd_p2_cfg(const ConvArgsP2& a, int splits, size_t lds, hipStream_t st) {
   auto kern = conv_fwd_bf16p2_kernel<LOG2W, BM, UP2>;
@@ -324,7 +633,19 @@ static void launch_fwd_p2_cfg(const ConvArgsP2& a, int splits, size_t lds, hipSt
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr = lds;
   }
-  dim3 grid(cdiv(a.nt, 8) * 8 * a.mt, splits);
+  const int ids = cdiv(a.nt, 8) * 8 * a.mt;
+  if (!a.stats && ids > band_persistent_blocks() && band_persistent_blocks() > 0) {
+    // more tiles than CUs: persistent blocks (one per CU) that prefetch the next tile's band under the current MFMAs
+    auto pk = conv_fwd_bf16p3_kernel<LOG2W, BM, UP2>;
+    static size_t pattr = 0;
+    if (pattr < lds) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pk), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      pattr = lds;
+    }
+    launch_timed(pk, dim3(band_persistent_blocks(), splits), dim3(768), lds, st, a);
+    return;
+  }
+  dim3 grid(ids, splits);
   launch_timed(kern, grid, dim3(768), lds, st, a);
 }
 template <int LOG2W>

@@ -2334,7 +2334,24 @@ int itcv_split_planes(const float* x, void* planes, int B, int C, int HW, int ns
 // ([ns][B][Ci/8][Hs][Ws] 16-byte chunks; Hs,Ws = H/2,W/2 when up2).  Workspace: itcv_conv2d_fwd_bf16s_workspace.
 int itcv_conv2d_fwd_bf16p(const void* xplanes, const void* wp, const float* bias, float* y, int B, int Ci, int H,
                           int W, int Co, int KS, int up2, int ns, void* ws, size_t ws_bytes, void* stream) {
+  return itcv_conv2d_fwd_bf16p_st(xplanes, wp, bias, y, B, Ci, H, W, Co, KS, up2, ns, nullptr, ws, ws_bytes, stream);
+}
+
+// Number of pixel tiles for which itcv_conv2d_fwd_bf16p_st reports per-channel output sums (0: the kernel chosen for
+// this shape cannot -- split-K slabs, or a tile form without the staged epilogue).
+int itcv_conv2d_fwd_bf16p_stat_tiles(int B, int Ci, int H, int W, int Co, int KS, int ns) {
+  if (B <= 0 || Ci <= 0 || H <= 0 || W <= 0 || Co <= 0 || !itcv_conv2d_bf16s_supported(Ci, Co, KS)) return 0;
+  const FwdPlanP2 p2 = plan_fwd_p2(B, Ci, H, W, Co, KS, ns);
+  return (p2.ok && p2.splits == 1) ? p2.nt : 0;
+}
+
+int itcv_conv2d_fwd_bf16p_st(const void* xplanes, const void* wp, const float* bias, float* y, int B, int Ci, int H,
+                             int W, int Co, int KS, int up2, int ns, float* tile_stats, void* ws, size_t ws_bytes,
+                             void* stream) {
   if (int e = check_dims("itcv_conv2d_fwd_bf16p", B, Ci, H, W, Co, KS)) return e;
+  if (tile_stats && !itcv_conv2d_fwd_bf16p_stat_tiles(B, Ci, H, W, Co, KS, ns))
+    return fail("%s: tile statistics are not available for this shape (see itcv_conv2d_fwd_bf16p_stat_tiles)",
+                "itcv_conv2d_fwd_bf16p_st");
   ITCV_REQUIRE(xplanes && wp && y && (ns == 2 || ns == 3), "itcv_conv2d_fwd_bf16p");
   if (!itcv_conv2d_bf16s_supported(Ci, Co, KS))
     return fail("%s: shape not supported by the split-bf16 kernel (Ci %% 32, Co > 32, KS 1/3)", "itcv_conv2d_fwd_bf16p");
@@ -2356,6 +2373,7 @@ int itcv_conv2d_fwd_bf16p(const void* xplanes, const void* wp, const float* bias
     a.mt = p2.mt, a.nt = p2.nt, a.cpt = p2.cpt, a.cpt_per_split = p2.cps;
     a.SR = p2.SR, a.NSEG = p2.NSEG, a.NP = p2.NP, a.NPC = p2.NPC, a.PXB = p2.PXB;
     a.h_shift = log2_exact(H);
+    a.stats = tile_stats, a.stat_T = p2.nt;
     a.slab_stride = p2.splits > 1 ? out_elems : 0;
     a.plane_stride = (size_t)B * (Ci / 8) * (up2 ? (H / 2) * (W / 2) : H * W);
 #ifdef ITCV_DIAG

@@ -67,6 +67,8 @@ struct ConvArgsP2 {
   int cpt, cpt_per_split;        // 32-channel groups, and how many of them one split-K slice takes
   int SR, NSEG, NP, NPC, PXB;    // band geometry: segment rows, segments, halo pixels, 64-chunk pieces, LDS row stride
   int h_shift;
+  float* stats;                  // optional [2][Co][stat_T]: per-tile sum / sum of squares of the output (BatchNorm statistics)
+  int stat_T;
   size_t slab_stride, plane_stride;
 #ifdef ITCV_DIAG
   int debug;   // diagnostic only (ITCV_ABLATE & 64): block 0 / 100 report main-loop shader cycles and 100 MHz ticks in y[0..3]

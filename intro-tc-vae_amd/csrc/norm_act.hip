@@ -97,6 +97,34 @@ __global__ void bn_finalize_kernel(const double* __restrict__ sums, double count
   }
 }
 
+// statistics from the per-tile sums a conv epilogue wrote (fp32 per 256-value tile, folded here in fp64): block per channel
+__global__ __launch_bounds__(256) void bn_tile_stats_finalize_kernel(const float* __restrict__ ts, int tiles, int pitch,
+                                                                    double count, float eps, float momentum,
+                                                                    float* running_mean, float* running_var, int64_t* nbt,
+                                                                    float* mean, float* rstd, int C) {
+  __shared__ double scratch[4];
+  const int c = blockIdx.x;
+  const float* p1 = ts + (size_t)c * pitch;
+  const float* p2 = ts + ((size_t)C + c) * pitch;
+  double s1 = 0.0, s2 = 0.0;
+  for (int t = threadIdx.x; t < tiles; t += 256) s1 += (double)p1[t], s2 += (double)p2[t];
+  s1 = block_sum(s1, scratch);
+  s2 = block_sum(s2, scratch);
+  if (threadIdx.x == 0) {
+    const double m = s1 / count;
+    double var = s2 / count - m * m;
+    if (var < 0.0) var = 0.0;
+    mean[c] = (float)m;
+    rstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+    if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)m;
+    if (running_var) {
+      const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+      running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+    }
+    if (c == 0 && nbt) nbt[0] += 1;
+  }
+}
+
 // single-rank fast path: fold the partial sums and finalise in one launch
 __global__ void bn_combine_finalize_kernel(const double* __restrict__ part, int splits, double count, float eps,
                                            float momentum, float* running_mean, float* running_var, int64_t* nbt,
@@ -896,9 +924,17 @@ int itcv_bn_act_bwd_apply(const float* x, const float* dy, const float* mean, co
 int itcv_bn_train_fwd(const float* x, const float* gamma, const float* beta, const float* skip, float* y, void* planes,
                       int ns, int B, int C, int H, int W, float slope, int pool, float eps, float momentum,
                       float* running_mean, float* running_var, int64_t* num_batches_tracked, float* mean, float* rstd,
-                      void* ws, size_t ws_bytes, size_t plane_stride, void* stream) {
+                      void* ws, size_t ws_bytes, size_t plane_stride, const float* tile_stats, int tiles, int tile_pitch,
+                      void* stream) {
   ITCV_REQUIRE(x && gamma && beta && mean && rstd && (y || planes) && B > 0 && C > 0 && H > 0 && W > 0, "itcv_bn_train_fwd");
   const size_t pstride = plane_stride ? plane_stride : (size_t)B * (C / 8) * (pool ? (H / 2) * (W / 2) : H * W);
+  if (tile_stats) {   // statistics come from the producing conv's epilogue: fold the tiles, then one apply pass
+    ITCV_REQUIRE(tiles > 0 && tile_pitch >= tiles, "itcv_bn_train_fwd(tile statistics)");
+    hipLaunchKernelGGL(bn_tile_stats_finalize_kernel, dim3(C), dim3(256), 0, S(stream), tile_stats, tiles, tile_pitch,
+                       (double)B * H * W, eps, momentum, running_mean, running_var, num_batches_tracked, mean, rstd, C);
+    ITCV_CHECK_LAUNCH("itcv_bn_train_fwd(tile statistics)");
+    return itcv_bn_act_fwd(x, mean, rstd, gamma, beta, skip, y, B, C, H, W, slope, pool, planes, ns, plane_stride, stream);
+  }
   const int HW = H * W, splits = bn_splits(B, C, HW);
   const int per_plane = pool ? (HW / 4) / 2 : HW / 4;
   const bool fusable = planes && (ns == 2 || ns == 3) && itcv_bn_act_planes_supported(C, H, W, pool) && splits > 1 &&

@@ -45,6 +45,8 @@ SIGNATURES = {
     "itcv_split_planes": (i32, [p, p, i32, i32, i32, i32, p]),
     "itcv_conv2d_fwd_bf16p_workspace": (sz, [i32] * 7),
     "itcv_conv2d_fwd_bf16p": (i32, [p, p, p, p] + [i32] * 8 + [p, sz, p]),
+    "itcv_conv2d_fwd_bf16p_stat_tiles": (i32, [i32] * 7),
+    "itcv_conv2d_fwd_bf16p_st": (i32, [p, p, p, p] + [i32] * 8 + [p, p, sz, p]),
     "itcv_conv2d_wgrad_bf16p_supported": (i32, [i32] * 6),
     "itcv_conv2d_wgrad_bf16p_workspace": (sz, [i32] * 6),
     "itcv_conv2d_wgrad_bf16p": (i32, [p, p, p] + [i32] * 8 + [p, sz, p]),
@@ -80,7 +82,8 @@ SIGNATURES = {
                                      p]),
     "itcv_bn_act_bwd_apply": (i32, [p, p, p, p, p, p, p, p, p, f64, p, p, p, p, i32, i32, i32, i32, i32, f32,
                                     i32, i32, p, i32, sz, p]),
-    "itcv_bn_train_fwd": (i32, [p, p, p, p, p, p, i32, i32, i32, i32, i32, f32, i32, f32, f32, p, p, p, p, p, p, sz, sz, p]),
+    "itcv_bn_train_fwd": (i32, [p, p, p, p, p, p, i32, i32, i32, i32, i32, f32, i32, f32, f32, p, p, p, p, p, p, sz, sz, p, i32, i32,
+                                p]),
     "itcv_bn_train_bwd": (i32, [p, p, p, p, p, p, p, p, p, p, p, i32, p, p, i32, i32, i32, i32, i32, f32, i32, i32, p,
                                 sz, sz, p]),
     "itcv_lrelu_fwd": (i32, [p, p, sz, f32, p]),
@@ -154,7 +157,7 @@ class _Lib:
     ``*_variant``: integers in, integer out, no device work) memoised: an eager step asks several thousand such
     questions, and a dict hit is ~10x cheaper than a ctypes call."""
 
-    _PURE = ("_supported", "_workspace", "_bytes", "_elems", "_variant")
+    _PURE = ("_supported", "_workspace", "_bytes", "_elems", "_variant", "_stat_tiles")
 
     def __init__(self, cdll):
         object.__setattr__(self, "_cdll", cdll)

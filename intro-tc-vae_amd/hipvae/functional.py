@@ -217,8 +217,16 @@ def split_planes(x, ns):
     return xp
 
 
-def conv_apply_planes(xp, weight, w4, for_dgrad, bias, B, Ci, H, W, Co, KS, up2, ns):
-    """conv_apply with the input given as pre-split planes (LDS-DMA kernel, no gather)."""
+# BatchNorm statistics from the conv epilogue (itcv_conv2d_fwd_bf16p_st).  OFF by default: measured, the staged epilogue
+# that produces them costs the band kernel more (+8 % on the 64-channel layers) than the statistics pass it replaces
+# saves -- that pass reads the conv output out of the Infinity Cache right behind the conv (4-10 us) -- see DESIGN.md.
+_FUSE_STATS = [_os.environ.get("ITCV_FUSE_BN_STATS", "0") == "1"]
+
+
+def conv_apply_planes(xp, weight, w4, for_dgrad, bias, B, Ci, H, W, Co, KS, up2, ns, want_stats=False):
+    """conv_apply with the input given as pre-split planes (LDS-DMA kernel, no gather).  ``want_stats``: where the
+    kernel can, it also leaves the per-tile channel sums of its output for the BatchNorm that follows
+    (attached to the result as ``_itcv_tile_stats``; BnActFn then skips its own statistics pass)."""
     if not up2 and ns == 2 and lib.itcv_conv2d_small_cout_bf16p_supported(Ci, Co, KS):
         y = torch.empty((B, Co, H, W), dtype=F32, device=xp.device)
         call("itcv_conv2d_small_cout_fwd_bf16p", ptr(xp), ptr(w4), ptr(bias), ptr(y), B, Ci, H, W, Co, KS, int(for_dgrad),
@@ -228,10 +236,25 @@ def conv_apply_planes(xp, weight, w4, for_dgrad, bias, B, Ci, H, W, Co, KS, up2,
     y = torch.empty((B, Co, H, W), dtype=F32, device=xp.device)
     nws = lib.itcv_conv2d_fwd_bf16p_workspace(B, Ci, H, W, Co, KS, ns)
     ws = _ws(nws, xp.device) if nws else None
-
-    call("itcv_conv2d_fwd_bf16p", ptr(xp), ptr(wp), ptr(bias), ptr(y), B, Ci, H, W, Co, KS, int(up2), ns, ptr(ws), nws,
-         stream())
+    T = lib.itcv_conv2d_fwd_bf16p_stat_tiles(B, Ci, H, W, Co, KS, ns) if (want_stats and _FUSE_STATS[0]) else 0
+    stats = torch.empty((2, Co, T), dtype=F32, device=xp.device) if T else None
+    call("itcv_conv2d_fwd_bf16p_st", ptr(xp), ptr(wp), ptr(bias), ptr(y), B, Ci, H, W, Co, KS, int(up2), ns, ptr(stats),
+         ptr(ws), nws, stream())
+    if stats is not None:
+        y._itcv_tile_stats = (stats, T, 256, y._version, y.data_ptr())     # 256 = (image, pixel) positions per tile
     return y
+
+
+def _tile_stats_of(x, B, G, HW):
+    """(stats, tiles per group, pitch) when ``x`` carries the producing conv's per-tile channel sums and the BatchNorm
+    groups are whole numbers of tiles, else None."""
+    tag = getattr(x, "_itcv_tile_stats", None)
+    if tag is None or tag[3] != x._version or tag[4] != x.data_ptr():
+        return None
+    stats, T, px = tag[0], tag[1], tag[2]
+    if T * px != B * HW or (B // G * HW) % px:
+        return None
+    return stats, T // G, T
 
 
 def conv_wgrad_planes(xp, dyp, B, Ci, H, W, Co, KS, up2, out=None, accumulate=False):
@@ -456,7 +479,7 @@ class Conv2dFn(Function):
         xp = None
         if ns:
             xp = planes_of(x, ns)
-            y = conv_apply_planes(xp, weight, weight, 0, b, B, Ci, H, W, Co, KS, up2, ns)
+            y = conv_apply_planes(xp, weight, weight, 0, b, B, Ci, H, W, Co, KS, up2, ns, want_stats=True)
         else:
             y = conv_apply(_require_fp32(x, "Conv2dFn.forward"), weight, weight, 0, b, B, Ci, H, W, Co, KS, up2)
         wg_planes = _wgrad_planes_ok(B, Ci, H, W, Co, KS)
@@ -608,6 +631,7 @@ class BnActFn(Function):
             pstride = B * (C // 8) * oshape[2] * oshape[3]            # chunks between planes of the WHOLE tensor
         write_y = out_fp32 or yp is None or _POISON[0]
         nws = lib.itcv_bn_workspace(Bg, C, H * W)
+        ts = _tile_stats_of(x, B, G, H * W) if (training and world == 1) else None
         for g in range(G):
             r = slice(g * Bg, (g + 1) * Bg)
             xg, yg = x[r], (y[r] if write_y else None)
@@ -616,9 +640,11 @@ class BnActFn(Function):
             if training and world == 1:
                 # statistics + apply in one call (the apply launch folds the sliced reduction where it can)
                 ws = _ws(nws, dev)
+                tsp = None if ts is None else ts[0].data_ptr() + 4 * g * ts[1]      # this group's tiles
                 call("itcv_bn_train_fwd", ptr(xg), ptr(gamma), ptr(beta), ptr(sg), ptr(yg), ptr(ypg), int(out_planes), Bg,
                      C, H, W, float(slope), int(pool), float(eps), float(momentum), ptr(running_mean), ptr(running_var),
-                     ptr(nbt), ptr(mean[g]), ptr(rstd[g]), ptr(ws), nws, pstride, stream())
+                     ptr(nbt), ptr(mean[g]), ptr(rstd[g]), ptr(ws), nws, pstride, tsp, ts[1] if ts else 0,
+                     ts[2] if ts else 0, stream())
                 continue
             if training:
                 ws = _ws(nws, dev)

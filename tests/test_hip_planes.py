@@ -169,3 +169,34 @@ def test_wgrad5_on_planes(HF, B, S, Cs, stem):
     acc = HF.conv_wgrad5_planes(small.to(dev()), bp, B, Cs, S, S, stem, out=dw.clone(), accumulate=True)
     assert rel_err(acc, 2 * ref) < 5e-5
     assert torch.equal(dw, HF.conv_wgrad5_planes(small.to(dev()), bp, B, Cs, S, S, stem))
+
+
+@pytest.mark.parametrize("shape", [(8, 64, 64, 64, 64), (4, 128, 32, 32, 128), (16, 64, 16, 16, 256), (64, 32, 8, 8, 64)])
+@pytest.mark.parametrize("groups", [1, 2])
+def test_batchnorm_statistics_from_the_conv_epilogue(HF, shape, groups):
+    """conv -> BatchNorm with the statistics taken from the conv epilogue's per-tile channel sums (fp32 per 256-value
+    tile, fp64 across tiles) == the statistics pass over the tensor (fp64 throughout): mean / rstd to 1e-6 of their
+    scale, the normalised output to 2e-6, running buffers alike; also per BatchNorm group."""
+    B, Ci, H, W, Co = shape
+    g = torch.Generator().manual_seed(sum(shape))
+    d = dev()
+    x = torch.randn(B, Ci, H, W, generator=g).to(d)
+    w = (torch.randn(Co, Ci, 3, 3, generator=g) / (3 * Ci ** 0.5)).to(d)
+    gamma, beta = (torch.rand(Co, generator=g) + 0.5).to(d), torch.randn(Co, generator=g).to(d)
+    HF.set_conv_math("bf16x3")
+    try:
+        res = {}
+        for fused in (True, False):
+            HF._FUSE_STATS[0] = fused
+            y = HF.Conv2dFn.apply(x, w, None, False)
+            assert (getattr(y, "_itcv_tile_stats", None) is not None) == (fused and bool(
+                HF.lib.itcv_conv2d_fwd_bf16p_stat_tiles(B, Ci, H, W, Co, 3, 2)))
+            rm, rv, nbt = torch.zeros(Co, device=d), torch.ones(Co, device=d), torch.zeros((), dtype=torch.long, device=d)
+            out = HF.BnActFn.apply(y, gamma, beta, None, rm, rv, nbt, 1e-4, 0.1, 0.2, False, True, None, 2, 0, True, True, groups)
+            res[fused] = (y.clone(), out.clone(), rm, rv, int(nbt), HF._tagged_planes(out, 2).clone())
+    finally:
+        HF._FUSE_STATS[0] = False
+        HF.set_conv_math("fp32")
+    a, b = res[True], res[False]
+    assert torch.equal(a[0], b[0])                       # the conv output itself is unchanged
+    assert rel_err(a[1], b[1]) < 2e-6 and rel_err(a[2], b[2]) < 1e-6 and rel_err(a[3], b[3]) < 1e-6 and a[4] == b[4] == groups
