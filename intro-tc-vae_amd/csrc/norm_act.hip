@@ -235,6 +235,29 @@ struct BnStatsIn {
   float* rstd_out;
 };
 
+// Plane stores of a wave: every thread holds PX consecutive 16-byte chunks (its PX pixels) per plane.  Stored straight
+// from the registers, one wave instruction writes 64 pieces of 16 bytes that lie PX*16 bytes apart -- every 128-byte line
+// is touched by PX instructions, two lanes each.  Instead the wave's PX*64 chunks pass through a wave-private LDS strip
+// in pixel order and every store instruction writes 1 KB of consecutive chunks.  `cidx0`: the wave's first thread index
+// (idx of lane 0); thread index -> (bc8, pp) as in the callers: chunk n of the wave belongs to thread cidx0 + n / PX.
+template <int PX, int NS>
+__device__ __forceinline__ void store_planes_wave(u32x4* __restrict__ planes, size_t plane_stride, uint32_t per_plane,
+                                                  uint32_t HWo, uint32_t cidx0, const u32x4 (&ch)[PX][NS],
+                                                  u32x4* __restrict__ strip) {
+  const uint32_t lane = threadIdx.x & 63;
+#pragma unroll
+  for (int p = 0; p < NS; ++p) {
+#pragma unroll
+    for (int s = 0; s < PX; ++s) strip[lane * PX + s] = ch[s][p];
+#pragma unroll
+    for (int k = 0; k < PX; ++k) {
+      const uint32_t n = k * 64 + lane, idx2 = cidx0 + n / PX, s2 = n % PX;
+      const uint32_t bc8 = idx2 / per_plane, pp = idx2 - bc8 * per_plane;
+      planes[(size_t)p * plane_stride + (size_t)bc8 * HWo + (size_t)pp * PX + s2] = strip[n];
+    }
+  }
+}
+
 template <int POOL, int NS, bool STATS>
 __global__ __launch_bounds__(256) void bn_act_fwd_planes_kernel(
     const float* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ rstd,
@@ -242,9 +265,10 @@ __global__ __launch_bounds__(256) void bn_act_fwd_planes_kernel(
     float* __restrict__ y, u32x4* __restrict__ planes, int B, int C, int H, int W, float slope, BnStatsIn st,
     size_t plane_stride) {
   __shared__ float s_mean[STATS ? kStatCh : 1], s_rstd[STATS ? kStatCh : 1];
+  constexpr int PX = POOL ? 2 : 4;                      // output pixels per thread
+  __shared__ u32x4 strips[4][64 * PX];
   const int HW = H * W, C8 = C >> 3;
   const int Ho = POOL ? H / 2 : H, Wo = POOL ? W / 2 : W, HWo = Ho * Wo;
-  constexpr int PX = POOL ? 2 : 4;                      // output pixels per thread
   const uint32_t per_plane = (uint32_t)HWo / PX, total = (uint32_t)B * C8 * per_plane;
   for (uint32_t base = blockIdx.x * blockDim.x; base < total; base += gridDim.x * blockDim.x) {
     const uint32_t idx = base + threadIdx.x;
@@ -313,15 +337,22 @@ __global__ __launch_bounds__(256) void bn_act_fwd_planes_kernel(
         o[j][0] = r0, o[j][1] = r1;
       }
     }
+    u32x4 chk[PX][NS];
 #pragma unroll
     for (int px = 0; px < PX; ++px) {
       float v8[8];
 #pragma unroll
       for (int j = 0; j < 8; ++j) v8[j] = o[j][px];
-      u32x4 pl[NS];
-      split8<NS>(v8, pl);
+      split8<NS>(v8, chk[px]);
+    }
+    const uint32_t cidx0 = base + (threadIdx.x & ~63u);
+    if (cidx0 + 64 <= total) {   // whole wave in range (wave-uniform): coalesced plane stores
+      store_planes_wave<PX, NS>(planes, plane_stride, per_plane, (uint32_t)HWo, cidx0, chk, strips[threadIdx.x >> 6]);
+    } else {
 #pragma unroll
-      for (int p = 0; p < NS; ++p) planes[(size_t)p * plane_stride + (size_t)bc8 * HWo + (size_t)pp * PX + px] = pl[p];
+      for (int px = 0; px < PX; ++px)
+#pragma unroll
+        for (int p = 0; p < NS; ++p) planes[(size_t)p * plane_stride + (size_t)bc8 * HWo + (size_t)pp * PX + px] = chk[px][p];
     }
   }
 }
@@ -529,6 +560,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_planes(
     float* __restrict__ dskip, u32x4* __restrict__ planes, int B, int C, int H, int W, float slope, int w_shift,
     BnBwdSumsIn sm, size_t plane_stride) {
   __shared__ float s_m1[SUMS ? kStatCh : 1], s_m2[SUMS ? kStatCh : 1];
+  __shared__ u32x4 strips[4][64 * 4];
   const uint32_t HW = H * W, C8 = C >> 3, per_plane = HW / 4, total = (uint32_t)B * C8 * per_plane;
   for (uint32_t base = blockIdx.x * blockDim.x; base < total; base += gridDim.x * blockDim.x) {
     const uint32_t idx = base + threadIdx.x;
@@ -579,15 +611,22 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_planes(
       if (dskip) *reinterpret_cast<float4*>(dskip + i) = g;
       o[j][0] = d.x, o[j][1] = d.y, o[j][2] = d.z, o[j][3] = d.w;
     }
+    u32x4 chk[4][NS];
 #pragma unroll
     for (int px = 0; px < 4; ++px) {
       float v8[8];
 #pragma unroll
       for (int j = 0; j < 8; ++j) v8[j] = o[j][px];
-      u32x4 pl[NS];
-      split8<NS>(v8, pl);
+      split8<NS>(v8, chk[px]);
+    }
+    const uint32_t cidx0 = base + (threadIdx.x & ~63u);
+    if (cidx0 + 64 <= total) {   // whole wave in range (wave-uniform): coalesced plane stores
+      store_planes_wave<4, NS>(planes, plane_stride, per_plane, HW, cidx0, chk, strips[threadIdx.x >> 6]);
+    } else {
 #pragma unroll
-      for (int p = 0; p < NS; ++p) planes[(size_t)p * plane_stride + (size_t)bc8 * HW + hw + px] = pl[p];
+      for (int px = 0; px < 4; ++px)
+#pragma unroll
+        for (int p = 0; p < NS; ++p) planes[(size_t)p * plane_stride + (size_t)bc8 * HW + hw + px] = chk[px][p];
     }
   }
 }
