@@ -258,7 +258,7 @@ __device__ __forceinline__ void store_planes_wave(u32x4* __restrict__ planes, si
   }
 }
 
-template <int POOL, int NS, bool STATS>
+template <int POOL, int NS, bool STATS, bool STRIP = true>
 __global__ __launch_bounds__(256) void bn_act_fwd_planes_kernel(
     const float* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ rstd,
     const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ skip,
@@ -266,7 +266,7 @@ __global__ __launch_bounds__(256) void bn_act_fwd_planes_kernel(
     size_t plane_stride) {
   __shared__ float s_mean[STATS ? kStatCh : 1], s_rstd[STATS ? kStatCh : 1];
   constexpr int PX = POOL ? 2 : 4;                      // output pixels per thread
-  __shared__ u32x4 strips[4][64 * PX];
+  __shared__ u32x4 strips[STRIP ? 4 : 1][STRIP ? 64 * PX : 1];
   const int HW = H * W, C8 = C >> 3;
   const int Ho = POOL ? H / 2 : H, Wo = POOL ? W / 2 : W, HWo = Ho * Wo;
   const uint32_t per_plane = (uint32_t)HWo / PX, total = (uint32_t)B * C8 * per_plane;
@@ -346,8 +346,8 @@ __global__ __launch_bounds__(256) void bn_act_fwd_planes_kernel(
       split8<NS>(v8, chk[px]);
     }
     const uint32_t cidx0 = base + (threadIdx.x & ~63u);
-    if (cidx0 + 64 <= total) {   // whole wave in range (wave-uniform): coalesced plane stores
-      store_planes_wave<PX, NS>(planes, plane_stride, per_plane, (uint32_t)HWo, cidx0, chk, strips[threadIdx.x >> 6]);
+    if (STRIP && cidx0 + 64 <= total) {   // whole wave in range (wave-uniform): coalesced plane stores
+      store_planes_wave<PX, NS>(planes, plane_stride, per_plane, (uint32_t)HWo, cidx0, chk, strips[STRIP ? threadIdx.x >> 6 : 0]);
     } else {
 #pragma unroll
       for (int px = 0; px < PX; ++px)
@@ -552,7 +552,7 @@ struct BnBwdSumsIn {
   int accumulate;
 };
 
-template <int MODE, int NS, bool SUMS>
+template <int MODE, int NS, bool SUMS, bool STRIP = true>
 __global__ __launch_bounds__(256) void bn_bwd_apply_planes(
     const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ mean,
     const float* __restrict__ rstd, const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -560,7 +560,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_planes(
     float* __restrict__ dskip, u32x4* __restrict__ planes, int B, int C, int H, int W, float slope, int w_shift,
     BnBwdSumsIn sm, size_t plane_stride) {
   __shared__ float s_m1[SUMS ? kStatCh : 1], s_m2[SUMS ? kStatCh : 1];
-  __shared__ u32x4 strips[4][64 * 4];
+  __shared__ u32x4 strips[STRIP ? 4 : 1][STRIP ? 64 * 4 : 1];
   const uint32_t HW = H * W, C8 = C >> 3, per_plane = HW / 4, total = (uint32_t)B * C8 * per_plane;
   for (uint32_t base = blockIdx.x * blockDim.x; base < total; base += gridDim.x * blockDim.x) {
     const uint32_t idx = base + threadIdx.x;
@@ -620,8 +620,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_planes(
       split8<NS>(v8, chk[px]);
     }
     const uint32_t cidx0 = base + (threadIdx.x & ~63u);
-    if (cidx0 + 64 <= total) {   // whole wave in range (wave-uniform): coalesced plane stores
-      store_planes_wave<4, NS>(planes, plane_stride, per_plane, HW, cidx0, chk, strips[threadIdx.x >> 6]);
+    if (STRIP && cidx0 + 64 <= total) {   // whole wave in range (wave-uniform): coalesced plane stores
+      store_planes_wave<4, NS>(planes, plane_stride, per_plane, HW, cidx0, chk, strips[STRIP ? threadIdx.x >> 6 : 0]);
     } else {
 #pragma unroll
       for (int px = 0; px < 4; ++px)
@@ -714,6 +714,20 @@ static inline int grid_for(size_t n, int per_thread = 1) {
   size_t b = cdivz(cdivz(n, per_thread), 256);
   if (b > 256 * 8) b = 256 * 8;  // grid-stride the rest (>= 8 blocks per CU resident)
   return b < 1 ? 1 : (int)b;
+}
+
+// Which plane-store form the apply kernels use (see store_planes_wave): bit 0 forward, bit 1 backward with the gradient at
+// the same resolution, bit 2 backward through the pooling / upsampling adjoints.  ITCV_BN_STRIP overrides (diagnostic).
+static inline int bn_strip_mask() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("ITCV_BN_STRIP");
+    // measured on one box, whole c2 step (20 graph replays): mask 0: 19.75 ms, 1: 19.55, 5: 19.40, 7: 19.30.  (With
+    // cold caches -- tools/bn_bench.py flushes them -- the same-resolution backward is slower with the strip, the forward
+    // 61 -> 51 us: inside a step the tensors are partly cache resident and the store side matters more.)
+    v = e ? atoi(e) : 7;
+  }
+  return v;
 }
 
 static inline bool bn_fuse_finalize() {   // ITCV_BN_FUSE=0: always finalise in a separate launch (diagnostic)
@@ -824,8 +838,14 @@ int itcv_bn_act_fwd(const float* x, const float* mean, const float* rstd, const 
     u32x4* pl = static_cast<u32x4*>(planes);
     const size_t pstride = plane_stride ? plane_stride : (size_t)B * (C / 8) * (pool ? (H / 2) * (W / 2) : H * W);
 #define ITCV_FWD_PLANES(POOL_, NS_)                                                                                   \
-  hipLaunchKernelGGL((bn_act_fwd_planes_kernel<POOL_, NS_, false>), grid, blk, 0, S(stream), x, mean, rstd, gamma, beta, \
-                     skip, y, pl, B, C, H, W, slope, BnStatsIn{}, pstride)
+  do {                                                                                                                \
+    if (bn_strip_mask() & 1)                                                                                          \
+      hipLaunchKernelGGL((bn_act_fwd_planes_kernel<POOL_, NS_, false, true>), grid, blk, 0, S(stream), x, mean, rstd, gamma, \
+                         beta, skip, y, pl, B, C, H, W, slope, BnStatsIn{}, pstride);                                   \
+    else                                                                                                              \
+      hipLaunchKernelGGL((bn_act_fwd_planes_kernel<POOL_, NS_, false, false>), grid, blk, 0, S(stream), x, mean, rstd, gamma, \
+                         beta, skip, y, pl, B, C, H, W, slope, BnStatsIn{}, pstride);                                   \
+  } while (0)
     if (pool) {
       if (ns == 2) ITCV_FWD_PLANES(1, 2);
       else ITCV_FWD_PLANES(1, 3);
@@ -912,8 +932,14 @@ int itcv_bn_act_bwd_apply(const float* x, const float* dy, const float* mean, co
     const dim3 grid(grid_for(n / 32)), blk(256);
     u32x4* pl = static_cast<u32x4*>(dx_planes);
 #define ITCV_BWD_PLANES(MODE_, NS_)                                                                              \
-  hipLaunchKernelGGL((bn_bwd_apply_planes<MODE_, NS_, false>), grid, blk, 0, st, x, dy, mean, rstd, gamma, beta, skip,  \
-                     dsums, count, dx, dskip, pl, B, C, H, W, slope, wsh, BnBwdSumsIn{}, pstride)
+  do {                                                                                                           \
+    if (bn_strip_mask() & ((MODE_) == 0 ? 2 : 4))                                                                \
+      hipLaunchKernelGGL((bn_bwd_apply_planes<MODE_, NS_, false, true>), grid, blk, 0, st, x, dy, mean, rstd, gamma, beta, \
+                         skip, dsums, count, dx, dskip, pl, B, C, H, W, slope, wsh, BnBwdSumsIn{}, pstride);       \
+    else                                                                                                         \
+      hipLaunchKernelGGL((bn_bwd_apply_planes<MODE_, NS_, false, false>), grid, blk, 0, st, x, dy, mean, rstd, gamma, beta, \
+                         skip, dsums, count, dx, dskip, pl, B, C, H, W, slope, wsh, BnBwdSumsIn{}, pstride);       \
+  } while (0)
 #define ITCV_BWD_PLANES_NS(MODE_)        \
   do {                                   \
     if (ns == 2) ITCV_BWD_PLANES(MODE_, 2); \
@@ -994,8 +1020,14 @@ int itcv_bn_train_fwd(const float* x, const float* gamma, const float* beta, con
   const dim3 grid(grid_for(threads)), blk(256);
   u32x4* pl = static_cast<u32x4*>(planes);
 #define ITCV_FWD_FUSED(POOL_, NS_)                                                                                   \
-  hipLaunchKernelGGL((bn_act_fwd_planes_kernel<POOL_, NS_, true>), grid, blk, 0, S(stream), x, mean, rstd, gamma, beta, \
-                     skip, y, pl, B, C, H, W, slope, st, pstride)
+  do {                                                                                                                \
+    if (bn_strip_mask() & 1)                                                                                          \
+      hipLaunchKernelGGL((bn_act_fwd_planes_kernel<POOL_, NS_, true, true>), grid, blk, 0, S(stream), x, mean, rstd, gamma,  \
+                         beta, skip, y, pl, B, C, H, W, slope, st, pstride);                                            \
+    else                                                                                                              \
+      hipLaunchKernelGGL((bn_act_fwd_planes_kernel<POOL_, NS_, true, false>), grid, blk, 0, S(stream), x, mean, rstd, gamma, \
+                         beta, skip, y, pl, B, C, H, W, slope, st, pstride);                                            \
+  } while (0)
   if (pool) {
     if (ns == 2) ITCV_FWD_FUSED(1, 2);
     else ITCV_FWD_FUSED(1, 3);
@@ -1041,8 +1073,14 @@ int itcv_bn_train_bwd(const float* x, const float* dy, const float* mean, const 
   do {                                                                                                                \
     hipLaunchKernelGGL((bn_bwd_partial_v4<MODE_, false>), rgrid, dim3(kRedThreads), 0, st, x, dy, mean, rstd, gamma,   \
                        beta, skip, part, B, C, H, W, slope, splits, wsh, hwsh, BnBwdFinal{});                         \
-    hipLaunchKernelGGL((bn_bwd_apply_planes<MODE_, NS_, true>), agrid, blk, 0, st, x, dy, mean, rstd, gamma, beta, skip, \
-                       static_cast<const double*>(nullptr), count, dx, dskip, pl, B, C, H, W, slope, wsh, sm, pstride); \
+    if (bn_strip_mask() & ((MODE_) == 0 ? 2 : 4))                                                                     \
+      hipLaunchKernelGGL((bn_bwd_apply_planes<MODE_, NS_, true, true>), agrid, blk, 0, st, x, dy, mean, rstd, gamma, beta, \
+                         skip, static_cast<const double*>(nullptr), count, dx, dskip, pl, B, C, H, W, slope, wsh, sm,   \
+                         pstride);                                                                                     \
+    else                                                                                                              \
+      hipLaunchKernelGGL((bn_bwd_apply_planes<MODE_, NS_, true, false>), agrid, blk, 0, st, x, dy, mean, rstd, gamma, beta, \
+                         skip, static_cast<const double*>(nullptr), count, dx, dskip, pl, B, C, H, W, slope, wsh, sm,   \
+                         pstride);                                                                                     \
   } while (0)
 #define ITCV_BWD_FUSED_NS(MODE_)            \
   do {                                      \
