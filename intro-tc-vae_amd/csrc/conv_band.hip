@@ -300,13 +300,17 @@ __global__ __launch_bounds__(768) void conv_fwd_bf16p2_kernel(ConvArgsP2 a) {
 // become free (and the weight ring simply wraps to the next tile's first taps), and the MFMA waves' result stores of
 // tile t drain while tile t+1 is multiplied.  Barrier structure, counted waits, K order and arithmetic are those of the
 // one-tile kernel (bit-identical results).
-template <int LOG2W, int BM, bool UP2>
+template <int LOG2W, int BM, bool UP2, int BN>
 __global__ __launch_bounds__(768) void conv_fwd_bf16p3_kernel(ConvArgsP2 a) {
-  constexpr int W = 1 << LOG2W, WP = W + 2, BN = 256, KC = 4, NS = 2;
-  constexpr int WM = BM / 64, WN = 8 / WM, WTN = BN / WN, TM = 2, TN = WTN / 32;
+  // BN = 256 pixels per tile for W <= 64 (whole rows); BN = 128 for 128- and 256-wide images: one row, or one half of a
+  // row whose band then takes its halo columns from the neighbouring half instead of the zero padding
+  constexpr int W = 1 << LOG2W, WB = W < BN ? W : BN, LOG2WB = LOG2W < 7 ? LOG2W : 7, WP = WB + 2, KC = 4, NS = 2;
+  static_assert(WB == (1 << LOG2WB) && (BN == 256 || BN == 128), "band width");
+  constexpr int WM = BN == 256 ? BM / 64 : 2, WN = 8 / WM, WTN = BN / WN, TM = BM / (32 * WM), TN = WTN / 32;
+  static_assert(TM >= 1 && TN >= 1 && WTN == 32 * TN, "wave tiling");
   constexpr int ASZ = NS * KC * BM;
   constexpr int PA = NS * KC * BM / 64 / 4;
-  constexpr int G = BM == 64 ? 2 : 1, NSTG = (9 + G - 1) / G;
+  constexpr int G = band_taps_per_stage(BM, BN), NSTG = (9 + G - 1) / G;
   extern __shared__ u32x4 smem[];
 
   const int t = threadIdx.x, lane = t & 63;
@@ -343,7 +347,7 @@ __global__ __launch_bounds__(768) void conv_fwd_bf16p3_kernel(ConvArgsP2 a) {
     long long soff[8], soff_n[8];
     uint32_t vmask = 0, vmask_n = 0;
     auto band_offsets = [&](int id, long long (&so)[8], uint32_t& vm) {
-      const int R0 = (tile_n_of(id) * BN) >> LOG2W;
+      const int pix0 = tile_n_of(id) * BN, R0 = pix0 >> LOG2W, col0 = pix0 & (W - 1);   // col0 != 0 only for W > BN
       vm = 0;
 #pragma unroll
       for (int qq = 0; qq < 8; ++qq) {
@@ -351,7 +355,7 @@ __global__ __launch_bounds__(768) void conv_fwd_bf16p3_kernel(ConvArgsP2 a) {
         so[qq] = 0;
         if (qq < a.NPC && hp < a.NP) {
           const int seg = hp / seg_px, rem = hp - seg * seg_px, hr = rem / WP, hc = rem - hr * WP;
-          const int grow = R0 + seg * a.SR, b = grow >> a.h_shift, h = (grow & (H - 1)) + hr - 1, wv = hc - 1;
+          const int grow = R0 + seg * a.SR, b = grow >> a.h_shift, h = (grow & (H - 1)) + hr - 1, wv = col0 + hc - 1;
           if (b < a.B && (unsigned)h < (unsigned)H && (unsigned)wv < (unsigned)W) {
             vm |= 1u << qq;
             so[qq] = (long long)b * C8 * HWs + (UP2 ? (h >> 1) * Ws + (wv >> 1) : h * W + wv);
@@ -460,11 +464,11 @@ __global__ __launch_bounds__(768) void conv_fwd_bf16p3_kernel(ConvArgsP2 a) {
   uint32_t hoff[TN];
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
-    const int nl = wn * WTN + j * 32 + l31, R = nl >> LOG2W, w = nl & (W - 1);
+    const int nl = wn * WTN + j * 32 + l31, R = nl >> LOG2WB, w = nl & (WB - 1);
     const int seg = R / a.SR, rr = R - seg * a.SR;
     hoff[j] = (uint32_t)((seg * (a.SR + 2) + rr + 1) * WP + w + 1) * 16u;
   }
-  const uint32_t aoff = (uint32_t)(wm * 64 + l31) * 16u;
+  const uint32_t aoff = (uint32_t)(wm * 32 * TM + l31) * 16u;
   __builtin_amdgcn_s_barrier();
   int buf = 0, slot = 0;
   while (tcur < nids) {
@@ -543,7 +547,7 @@ __global__ __launch_bounds__(768) void conv_fwd_bf16p3_kernel(ConvArgsP2 a) {
       for (int i = 0; i < TM; ++i) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+          const int m = m0 + wm * 32 * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
           if (m < a.Co) {
             float v = acc[i][j][r];
             if (a.bias) v += a.bias[m];
@@ -568,26 +572,27 @@ FwdPlanP2 plan_fwd_p2(int B, int Ci, int H, int W, int Co, int KS, int ns) {
   FwdPlanP2 p;
   memset(&p, 0, sizeof(p));
   const int lw = log2_exact(W), lh = log2_exact(H);
-  if (KS != 3 || ns != 2 || lw < 3 || lw > 6 || lh < 0 || Ci % 32 || Co < 33) return p;
+  if (KS != 3 || ns != 2 || lw < 3 || lw > 8 || lh < 0 || Ci % 32 || Co < 33) return p;
+  p.bn = lw > 6 ? 128 : 256;     // 128- and 256-wide images: 128-pixel tiles (one row / half a row), persistent kernel only
   static int enabled = -1;
   if (enabled < 0) {
     const char* e = getenv("ITCV_BF16P2");
     enabled = (e && e[0] == '0') ? 0 : 1;
   }
   if (!enabled) return p;
-  const int NR = 256 / W;
+  const int WBh = W < p.bn ? W : p.bn, NR = p.bn / WBh;
   p.SR = NR < H ? NR : H;
   p.NSEG = NR / p.SR;
-  p.NP = p.NSEG * (p.SR + 2) * (W + 2);
+  p.NP = p.NSEG * (p.SR + 2) * (WBh + 2);
   p.NPC = cdiv(p.NP, 64);
   p.PXB = p.NPC * 64;
   if (p.NPC > 7) return p;
-  p.nt = (int)(((long long)B * H * W + 255) / 256);
+  p.nt = (int)(((long long)B * H * W + p.bn - 1) / p.bn);
   p.bm = Co <= 64 ? 64 : 128;
   // mid-sized layers: 64-row tiles when that fills the chip without split-K and 128-row tiles would not
   if (p.bm == 128 && cdiv(Co, 128) * p.nt < 192 && cdiv(Co, 64) * p.nt >= 192 && p2_bm64_mid()) p.bm = 64;
-  p.lds = ((size_t)3 * (p.bm == 64 ? 2 : 1) * 2 * 4 * p.bm + (size_t)2 * 2 * 4 * p.PXB) * 16;   // [3][G] weight ring + 2 bands
-  const size_t stage_bytes = (size_t)p.bm * (256 + 4) * sizeof(float);   // the epilogue's staging tile reuses the allocation
+  p.lds = ((size_t)3 * band_taps_per_stage(p.bm, p.bn) * 2 * 4 * p.bm + (size_t)2 * 2 * 4 * p.PXB) * 16;   // [3][G] weight ring + 2 bands
+  const size_t stage_bytes = p.bn == 256 ? (size_t)p.bm * (256 + 4) * sizeof(float) : 0;   // the staged epilogue's tile reuses the allocation
   if (p.lds < stage_bytes) p.lds = stage_bytes;
   if (p.lds > 160 * 1024) return p;
   p.mt = cdiv(Co, p.bm);
@@ -636,7 +641,7 @@ static void launch_fwd_p2_cfg(const ConvArgsP2& a, int splits, size_t lds, hipSt
   const int ids = cdiv(a.nt, 8) * 8 * a.mt;
   if (!a.stats && ids > band_persistent_blocks() && band_persistent_blocks() > 0) {
     // more tiles than CUs: persistent blocks (one per CU) that prefetch the next tile's band under the current MFMAs
-    auto pk = conv_fwd_bf16p3_kernel<LOG2W, BM, UP2>;
+    auto pk = conv_fwd_bf16p3_kernel<LOG2W, BM, UP2, 256>;
     static size_t pattr = 0;
     if (pattr < lds) {
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pk), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -659,7 +664,35 @@ static void launch_fwd_p2_w(const ConvArgsP2& a, int bm, int up2, int splits, si
   }
 }
 
+// 128- / 256-wide images: the persistent kernel with 128-pixel tiles
+template <int LOG2W, int BM, bool UP2>
+static void launch_fwd_p3_wide_cfg(const ConvArgsP2& a, int splits, size_t lds, hipStream_t st) {
+  auto pk = conv_fwd_bf16p3_kernel<LOG2W, BM, UP2, 128>;
+  static size_t pattr = 0;
+  if (pattr < lds) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pk), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    pattr = lds;
+  }
+  const int ids = cdiv(a.nt, 8) * 8 * a.mt, nb = band_persistent_blocks() > 0 ? band_persistent_blocks() : 256;
+  launch_timed(pk, dim3(ids < nb ? ids : nb, splits), dim3(768), lds, st, a);
+}
+template <int LOG2W>
+static void launch_fwd_p3_wide(const ConvArgsP2& a, int bm, int up2, int splits, size_t lds, hipStream_t st) {
+  if (bm == 64) {
+    if (up2) launch_fwd_p3_wide_cfg<LOG2W, 64, true>(a, splits, lds, st);
+    else launch_fwd_p3_wide_cfg<LOG2W, 64, false>(a, splits, lds, st);
+  } else {
+    if (up2) launch_fwd_p3_wide_cfg<LOG2W, 128, true>(a, splits, lds, st);
+    else launch_fwd_p3_wide_cfg<LOG2W, 128, false>(a, splits, lds, st);
+  }
+}
+
 void launch_fwd_p2(const ConvArgsP2& a, const FwdPlanP2& p, int W, int up2, hipStream_t st) {
+  if (p.bn == 128) {
+    if (log2_exact(W) == 7) launch_fwd_p3_wide<7>(a, p.bm, up2, p.splits, p.lds, st);
+    else launch_fwd_p3_wide<8>(a, p.bm, up2, p.splits, p.lds, st);
+    return;
+  }
   switch (log2_exact(W)) {
     case 3: launch_fwd_p2_w<3>(a, p.bm, up2, p.splits, p.lds, st); break;
     case 4: launch_fwd_p2_w<4>(a, p.bm, up2, p.splits, p.lds, st); break;

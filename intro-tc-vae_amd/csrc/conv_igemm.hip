@@ -2342,7 +2342,7 @@ int itcv_conv2d_fwd_bf16p(const void* xplanes, const void* wp, const float* bias
 int itcv_conv2d_fwd_bf16p_stat_tiles(int B, int Ci, int H, int W, int Co, int KS, int ns) {
   if (B <= 0 || Ci <= 0 || H <= 0 || W <= 0 || Co <= 0 || !itcv_conv2d_bf16s_supported(Ci, Co, KS)) return 0;
   const FwdPlanP2 p2 = plan_fwd_p2(B, Ci, H, W, Co, KS, ns);
-  return (p2.ok && p2.splits == 1) ? p2.nt : 0;
+  return (p2.ok && p2.splits == 1 && p2.bn == 256) ? p2.nt : 0;
 }
 
 int itcv_conv2d_fwd_bf16p_st(const void* xplanes, const void* wp, const float* bias, float* y, int B, int Ci, int H,

@@ -75,8 +75,11 @@ struct ConvArgsP2 {
 #endif
 };
 
+// taps (K-tiles) per barrier stage of the band kernels: tiles with little MFMA work per tap take two
+__host__ __device__ constexpr int band_taps_per_stage(int bm, int bn) { return (bm == 64 || bn == 128) ? 2 : 1; }
+
 struct FwdPlanP2 {
-  int ok, bm, mt, nt, cpt, splits, cps, SR, NSEG, NP, NPC, PXB;
+  int ok, bm, bn, mt, nt, cpt, splits, cps, SR, NSEG, NP, NPC, PXB;
   size_t lds;
 };
 

@@ -50,6 +50,9 @@ def test_split_planes_reconstructs(HF, ns, tol):
 PLANES_CASES = [  # B, Ci, H, W, Co, up2 -- band kernel (W in 8..64), 128-pixel-tile kernel (W = 4), 64- and 128-row tiles
     (2, 64, 16, 16, 64, False), (2, 128, 8, 8, 160, False), (3, 32, 32, 32, 48, False), (2, 64, 64, 64, 64, False),
     (4, 128, 4, 4, 256, False), (2, 64, 16, 16, 128, True), (2, 96, 32, 32, 64, True),
+    # 128- and 256-wide images: 128-pixel tiles of the persistent band kernel (one row / half a row per tile)
+    (2, 64, 8, 128, 64, False), (1, 64, 8, 256, 64, False), (2, 32, 16, 128, 160, False), (1, 64, 8, 256, 64, True),
+    (3, 64, 4, 128, 128, True), (5, 64, 128, 128, 64, False),
 ]
 
 
