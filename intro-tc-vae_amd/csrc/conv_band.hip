@@ -325,8 +325,13 @@ __global__ __launch_bounds__(768) void conv_fwd_bf16p3_kernel(ConvArgsP2 a) {
   const uint32_t band_base = smem_base + 3u * G * ASZ * 16u;
   // tile ids of this block: id = blockIdx.x + k * gridDim.x over the padded id space of the one-tile kernel
   // (id & 7 = XCD slot, so a block keeps its XCD); ids whose N tile lies past the end are skipped -- by every wave alike
-  const int nids = ((a.nt + 7) >> 3) * 8 * a.mt, stride = gridDim.x;
-  auto tile_n_of = [&](int id) { return ((id >> 3) / a.mt) * 8 + (id & 7); };
+  // N tiles are dealt to the XCD slots in CONTIGUOUS ranges (slot x owns tiles x*R .. x*R+R-1): the blocks of one XCD
+  // then work on neighbouring row bands at any time and the halo rows two neighbouring tiles share are served by that
+  // XCD's L2 instead of being fetched once per tile from the Infinity Cache / HBM (speed only: nothing depends on
+  // where a block runs)
+  const int xr = (a.nt + 7) >> 3;
+  const int nids = xr * 8 * a.mt, stride = gridDim.x;
+  auto tile_n_of = [&](int id) { return (id & 7) * xr + (id >> 3) / a.mt; };
   auto tile_m_of = [&](int id) { return (id >> 3) % a.mt; };
   auto next_tile = [&](int id) {
     id += stride;
@@ -685,6 +690,11 @@ static void launch_fwd_p3_wide(const ConvArgsP2& a, int bm, int up2, int splits,
     if (up2) launch_fwd_p3_wide_cfg<LOG2W, 128, true>(a, splits, lds, st);
     else launch_fwd_p3_wide_cfg<LOG2W, 128, false>(a, splits, lds, st);
   }
+}
+
+bool band_is_persistent(const ConvArgsP2& a, const FwdPlanP2& p) {
+  const int ids = cdiv(a.nt, 8) * 8 * a.mt;
+  return p.bn == 128 || (!a.stats && band_persistent_blocks() > 0 && ids > band_persistent_blocks());
 }
 
 void launch_fwd_p2(const ConvArgsP2& a, const FwdPlanP2& p, int W, int up2, hipStream_t st) {

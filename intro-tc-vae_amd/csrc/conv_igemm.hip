@@ -1635,17 +1635,20 @@ __global__ __launch_bounds__(256) void conv_wgrad5_planes_kernel(const float* __
     for (int nt = 0; nt < 4; ++nt) acc[dh][nt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
   for (int h = h_lo; h < h_hi; ++h) {
-    // stage T row (b, h): 8 channel chunks x W pixels x 2 planes; lane = pixel (W <= 64)
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // previous row's fragment reads are done (wave-private buffer)
-    if (lane < W) {
+   for (int seg = 0; seg < W; seg += 64) {                  // rows wider than 64 pixels: one 64-pixel segment at a time
+    const int segw = min(64, W - seg);
+    // stage T row (b, h), columns seg .. seg+segw-1: 8 channel chunks x 2 planes; lane = pixel
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // previous segment's fragment reads are done (wave-private buffer)
+    if (lane < segw) {
 #pragma unroll
       for (int pl = 0; pl < 2; ++pl)
 #pragma unroll
         for (int c8 = 0; c8 < 8; ++c8)
-          rows[wv][(pl * 8 + c8) * PXS + lane] = tp[(size_t)pl * plane_stride + ((size_t)b * 8 + c8) * HW + (size_t)h * W + lane];
+          rows[wv][(pl * 8 + c8) * PXS + lane] =
+              tp[(size_t)pl * plane_stride + ((size_t)b * 8 + c8) * HW + (size_t)h * W + seg + lane];
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    for (int w0 = 0; w0 < W; w0 += 32) {
+    for (int w0 = 0; w0 < segw; w0 += 32) {
       // B fragments: T^T, columns = 16 channels of N-tile nt, k = pixels w0 + 8*kg + {0..7}
       bf16x8 bfr[4][2];
 #pragma unroll
@@ -1658,7 +1661,7 @@ __global__ __launch_bounds__(256) void conv_wgrad5_planes_kernel(const float* __
 #pragma unroll
       for (int dh = 0; dh < 5; ++dh) {
         // A fragment: S[b][cs][h + SG*(dh-2)][w0 + 8*kg + j + SG*(dw-2)], j = 0..7
-        const int hs = h + SG * (dh - 2), ws0 = w0 + 8 * kg + SG * (dw - 2);
+        const int hs = h + SG * (dh - 2), ws0 = seg + w0 + 8 * kg + SG * (dw - 2);
         float v[8];
         const bool hok = row_used && (unsigned)hs < (unsigned)H;
         const float* sp = sm + ((size_t)b * CS + (row_used ? cs : 0)) * HW + (size_t)(hok ? hs : 0) * W;
@@ -1680,6 +1683,7 @@ __global__ __launch_bounds__(256) void conv_wgrad5_planes_kernel(const float* __
         }
       }
     }
+   }
   }
   // slab[job][m = (cs,dw) 0..15][dh][cb 0..63]; lane: column n -> cb = nt*16 + n, rows m = 4*kg + i
   float* out = slab + (size_t)job * 16 * 5 * 64;
@@ -2381,7 +2385,8 @@ int itcv_conv2d_fwd_bf16p_st(const void* xplanes, const void* wp, const float* b
 #endif
     hipStream_t st = S(stream);
     {
-      ProfScope prof(st, 8, log2_exact(W), p2.bm, up2 ? 1 : 0, ns, 2.0 * B * H * W * (double)Co * Ci * KS * KS);
+      ProfScope prof(st, band_is_persistent(a, p2) ? 9 : 8, log2_exact(W), p2.bm, up2 ? 1 : 0, ns,
+                     2.0 * B * H * W * (double)Co * Ci * KS * KS);
       launch_fwd_p2(a, p2, W, up2, st);
     }
     ITCV_CHECK_LAUNCH("itcv_conv2d_fwd_bf16p(band)");
@@ -2704,7 +2709,7 @@ int itcv_linear_wgrad(const float* dy, const float* x, float* dw, int B, int K, 
 // stem = 1: dw[64][Cs][5][5] for x[B][Cs][H][W] (fp32, `small`) and the planes of dy[B][64][H][W] (`big_planes`);
 // stem = 0: dw[Cs][64][5][5] for dy[B][Cs][H][W] (fp32, `small`) and the planes of x[B][64][H][W].
 int itcv_conv2d_wgrad5_bf16p_supported(int Cs, int Cb, int H, int W) {
-  return Cs >= 1 && Cs <= 3 && Cb == 64 && H > 0 && W >= 32 && W <= 64 && W % 32 == 0;
+  return Cs >= 1 && Cs <= 3 && Cb == 64 && H > 0 && W >= 32 && W <= 256 && W % 32 == 0;
 }
 static inline int wgrad5_rows_per_job(int B, int H) {
   int r = cdiv(B * H, 1024);      // ~1024 wave jobs (256 blocks of 4)

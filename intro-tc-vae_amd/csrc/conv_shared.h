@@ -86,5 +86,6 @@ struct FwdPlanP2 {
 // conv_band.hip
 FwdPlanP2 plan_fwd_p2(int B, int Ci, int H, int W, int Co, int KS, int ns);
 void launch_fwd_p2(const ConvArgsP2& a, const FwdPlanP2& p, int W, int up2, hipStream_t st);
+bool band_is_persistent(const ConvArgsP2& a, const FwdPlanP2& p);   // will launch_fwd_p2 use the persistent kernel?
 
 }  // namespace itcv

@@ -281,7 +281,7 @@ class LaunchProfile:
     the launch stream around the main kernel of every conv call (bench.py's roofline leg)."""
     KINDS = {0: "conv_fwd_kernel", 1: "conv_fwd_bf16s_kernel", 2: "conv_wgrad_kernel", 3: "conv_wgrad_bf16s_kernel",
              4: "conv_small_cout_kernel", 5: "conv_small_cin_kernel", 6: "conv_fwd_bf16p_kernel",
-             7: "conv_wgrad_bf16p_kernel", 8: "conv_fwd_bf16p2_kernel"}
+             7: "conv_wgrad_bf16p_kernel", 8: "conv_fwd_bf16p2_kernel", 9: "conv_fwd_bf16p3_kernel"}
 
     @classmethod
     def begin(cls):
@@ -300,7 +300,7 @@ class LaunchProfile:
             kind, ks, bm, up2, ns = c & 15, (c >> 4) & 15, (c >> 8) & 255, (c >> 16) & 1, (c >> 20) & 15
             if kind in (0, 2):
                 label = f"{cls.KINDS[kind]}<KS={ks},BM={bm},up2={up2}>"
-            elif kind in (7, 8):   # templates <LOG2W, ...>: the KS field carries log2(W)
+            elif kind in (7, 8, 9):   # templates <LOG2W, ...>: the KS field carries log2(W); 9 = persistent band kernel
                 label = f"{cls.KINDS[kind]}<LOG2W={ks},BM={bm},up2={up2},NS={ns}>"
             elif kind in (1, 3, 6):
                 label = f"{cls.KINDS[kind]}<KS={ks},BM={bm},up2={up2},NS={ns}>"

@@ -155,7 +155,8 @@ def test_small_cout_conv_on_planes(HF, B, S, Co, dgrad):
     assert rel_err(got, ref) < 5e-5
 
 
-@pytest.mark.parametrize("B,S,Cs,stem", [(3, 32, 3, True), (2, 64, 3, False), (5, 32, 2, False), (2, 64, 1, True)])
+@pytest.mark.parametrize("B,S,Cs,stem", [(3, 32, 3, True), (2, 64, 3, False), (5, 32, 2, False), (2, 64, 1, True),
+                                          (1, 128, 3, True), (1, 128, 3, False), (1, 256, 3, True)])
 def test_wgrad5_on_planes(HF, B, S, Cs, stem):
     """5x5 weight gradient with a <= 3-channel side (stem / predict) on the bf16 matrix cores: rows (channel, dw),
     pixel reduction through the transposing LDS read -- against fp64 (bf16x3: 5e-5), accumulate form, bitwise repeatable."""

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""rocprofv3 --pmc passes -> profiles/r01_pmc_traffic.json (HBM bytes per launch of every kernel).
+"""rocprofv3 --pmc passes -> profiles/r02_pmc_traffic.json (HBM bytes per launch of every kernel).
 
     rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_fetch -o f -- python3 bench.py ...
     rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_write -o w -- python3 bench.py ...
@@ -11,6 +11,7 @@ coalesced reads (MI355X_MICROARCH.md, HBM section) -- both the raw and the x2-co
 """
 import csv
 import json
+import os
 import re
 import sys
 from collections import defaultdict
@@ -23,7 +24,10 @@ def fold(name):
     m = re.search(r"conv_fwd_bf16p2_kernel<(\d+), (\d+), (true|false)>", name)
     if m:
         return f"conv_fwd_bf16p2_kernel<LOG2W={m[1]},BM={m[2]},up2={int(m[3] == 'true')},NS=2>"
-    m = re.search(r"conv_wgrad_bf16p_kernel<(\d+), (true|false), (\d+)(?:, \d+)?>", name)
+    m = re.search(r"conv_fwd_bf16p3_kernel<(\d+), (\d+), (true|false), \d+>", name)
+    if m:
+        return f"conv_fwd_bf16p3_kernel<LOG2W={m[1]},BM={m[2]},up2={int(m[3] == 'true')},NS=2>"
+    m = re.search(r"conv_wgrad_bf16p_kernel<(\d+), (true|false), (\d+)(?:, \d+)*>", name)
     if m:
         return f"conv_wgrad_bf16p_kernel<LOG2W={m[1]},BM={m[3]},up2={int(m[2] == 'true')},NS=2>"
     m = re.search(r"itcv::(\w+)(<[^(]*>)?\(", name)
@@ -43,10 +47,13 @@ def collect(path, counter):
 
 
 def main():
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bench import csrc_digest
     fetch, write = collect(sys.argv[1], "FETCH_SIZE"), collect(sys.argv[2], "WRITE_SIZE")
     math = sys.argv[3] if len(sys.argv) > 3 else "bf16x3"
-    out = {"note": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over "
-                   "`bench.py --steps 2 --warmup 1 --no-graph --no-cpu-baseline`, c2 workload. KiB per launch averaged "
+    out = {"csrc_sha256": csrc_digest(),
+           "note": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over "
+                   "`bench.py --steps 2 --warmup 1 --no-graph --no-modes --no-cpu-baseline`, c2 workload. KiB per launch averaged "
                    "over all launches of the kernel; fetch_x2 applies the gfx950 FETCH_SIZE correction for wide "
                    "coalesced reads (16 B/lane LDS-DMA / dwordx4 loads, which is what the planes kernels issue).",
            "math": math, "kernels": {}}
