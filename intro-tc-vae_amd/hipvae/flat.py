@@ -6,6 +6,8 @@ data-parallel all-reduce are each ONE kernel / ONE collective per half instead o
 tensor (20 M parameters in ~100 tensors at the 64x64 configuration).  The nn.Parameter objects
 themselves are untouched, so optimizers and state_dicts that reference them stay valid.
 """
+import weakref
+
 import torch
 
 from .abi import call, lib, ptr, stream
@@ -39,7 +41,7 @@ class FlatGroup:
                 self.flat_p[o:o + n].copy_(p.data.reshape(-1))
                 p.data = self.flat_p[o:o + n].view(p.shape)
         self._ws = torch.empty(lib.itcv_sumsq_workspace(total), dtype=torch.uint8, device=dev)
-        self._opt = None
+        self._opt, self._parent = None, inherit
         self.attach_grads()
         if inherit is not None:
             self._inherit(inherit)
@@ -53,6 +55,8 @@ class FlatGroup:
                     n = p.numel()
                     self.exp_avg[o:o + n].copy_(old.exp_avg[src[0]:src[0] + n])
                     self.exp_avg_sq[o:o + n].copy_(old.exp_avg_sq[src[0]:src[0] + n])
+                    # the (possibly stale) gradients too: the clip norm runs over them (solvers/intro.py:113-115)
+                    self.flat_g[o:o + n].copy_(old.flat_g[src[0]:src[0] + n])
             self.step_dev.copy_(old.step_dev)
         self.step = old.step
 
@@ -65,21 +69,30 @@ class FlatGroup:
         if self._opt is opt:
             return
         self._opt = opt
-        self._adopt(opt)
+        prev = getattr(opt, "_itcv_group", None)
+        prev = prev() if prev is not None else None
+        opt._itcv_group = weakref.ref(self)
+        # state mirrored by the group these parameters came from was carried over by _inherit (with the device-side
+        # step count, which the mirror's ``step`` entries lag behind): only re-point the views then
+        self._adopt(opt, copy=not (prev is not None and prev is self._parent))
         if hasattr(opt, "register_state_dict_pre_hook"):
-            opt.register_state_dict_pre_hook(lambda o: self._refresh_steps(o))
-            opt.register_load_state_dict_post_hook(lambda o: self._adopt(o))
+            opt.register_state_dict_pre_hook(lambda o: self._refresh_steps(o) if self._current(o) else None)
+            opt.register_load_state_dict_post_hook(lambda o: self._adopt(o) if self._current(o) else None)
+
+    def _current(self, opt):
+        ref = getattr(opt, "_itcv_group", None)
+        return ref is not None and ref() is self
 
     def _mine(self, t, buf, o, n):
         return t is not None and t.data_ptr() == buf.data_ptr() + 4 * o and t.numel() == n and t.device == buf.device
 
-    def _adopt(self, opt):
+    def _adopt(self, opt, copy=True):
         step = None
         with torch.no_grad():
             for p, o in zip(self.params, self.offsets):
                 n = p.numel()
                 st = opt.state.get(p)
-                if st and "exp_avg" in st and not self._mine(st["exp_avg"], self.exp_avg, o, n):
+                if copy and st and "exp_avg" in st and not self._mine(st["exp_avg"], self.exp_avg, o, n):
                     self.exp_avg[o:o + n].copy_(st["exp_avg"].reshape(-1))
                     self.exp_avg_sq[o:o + n].copy_(st["exp_avg_sq"].reshape(-1))
                     step = int(st["step"]) if step is None else max(step, int(st["step"]))

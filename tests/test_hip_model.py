@@ -510,3 +510,55 @@ def test_batched_passes_equal_unbatched_step():
     assert float(((out[True][1] - out[False][1]).abs() > 1e-6).float().mean()) < 1e-3
     for k, v in out[False][2].items():
         assert rel_err(out[True][2][k], v) < 1e-5, k
+
+
+def test_adam_state_roundtrip_and_ownership_carryover():
+    """The fused Adam's moments live in flat buffers; they are mirrored into ``optimizer.state`` (so
+    ``optimizer.state_dict()`` / ``load_state_dict()`` round-trip) and carried over when the parameters are moved
+    out of the flat buffer (``model.float()`` / ``.to()`` / a manual re-point after the first step)."""
+    import ops
+    g = np.load(os.path.join(GOLDEN, "steps_conv.npz"))
+    hp = g["hp"]
+    draws = [[T(g[f"intro_tc:s{s}:draw{i}"]) for i in range(6)] for s in range(2)]
+    xs = [T(g["x0"]), T(g["x1"])]
+
+    def steps(solver, which):
+        out = []
+        for s in which:
+            with ops.noise_queue([t.clone() for t in draws[s]]):
+                out.append(solver.train_step(xs[s], s))
+        return out
+
+    # reference trajectory: step 0 then step 1, uninterrupted
+    m0 = build("conv", load_state(g, "init:"))
+    s0 = make_solver("intro_tc", m0, hp)
+    ref = steps(s0, (0, 1))
+    # (a) state_dict round trip after step 0 into a fresh model / optimizers
+    m1 = build("conv", load_state(g, "init:"))
+    s1 = make_solver("intro_tc", m1, hp)
+    first = steps(s1, (0,))
+    sd_e, sd_d, sd_m = s1.optimizer_e.state_dict(), s1.optimizer_d.state_dict(), m1.state_dict()
+    assert len(sd_e["state"]) == len(list(m1.encoder.parameters())) and int(sd_e["state"][0]["step"]) == 1
+    assert float(sd_e["state"][0]["exp_avg"].abs().max()) > 0
+    m2 = build("conv", {k: v.cpu() for k, v in sd_m.items()})
+    s2 = make_solver("intro_tc", m2, hp)
+    s2.optimizer_e.load_state_dict(sd_e)
+    s2.optimizer_d.load_state_dict(sd_d)
+    second = steps(s2, (1,))
+    assert first[0] == ref[0]
+    # L2 is left out: the clip norm runs over every parameter with a gradient (intro.py:113-115), and in the resumed run
+    # the frozen half's STALE gradients of the previous step are gone (the reference's checkpoints do not hold .grad either)
+    for k in ("loss_enc", "loss_dec", "loss_kl", "loss_rec"):
+        assert abs(second[0][k] - ref[1][k]) <= 1e-6 * abs(ref[1][k]), (k, second[0][k], ref[1][k])
+    # (b) ownership lost after step 0: parameters re-pointed out of the flat buffers
+    m3 = build("conv", load_state(g, "init:"))
+    s3 = make_solver("intro_tc", m3, hp)
+    steps(s3, (0,))
+    for p in m3.parameters():
+        p.data = p.data.clone()
+    third = steps(s3, (1,))
+    for k in ref[1]:
+        assert abs(third[0][k] - ref[1][k]) <= 1e-6 * abs(ref[1][k]), (k, third[0][k], ref[1][k])
+    wa = torch.cat([p.detach().reshape(-1) for p in m0.parameters()])
+    wb = torch.cat([p.detach().reshape(-1) for p in m3.parameters()])
+    assert float((wa - wb).abs().max()) < 1e-7
