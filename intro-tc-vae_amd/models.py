@@ -319,8 +319,10 @@ class Encoder(nn.Module):
         else:
             y = self.main(x)
         y = self.fc(y.reshape(x.size(0), -1))
+        # models.py:243 returns the two column halves as views; every latent kernel wants dense rows, so they are made
+        # contiguous ONCE here (a view would be copied again by each of the 3-6 ops that consume it)
         mu, logvar = y.chunk(2, dim=1)
-        return mu, logvar
+        return mu.contiguous(), logvar.contiguous()
 
 
 class Decoder(nn.Module):
