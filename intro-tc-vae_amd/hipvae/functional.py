@@ -60,7 +60,10 @@ def _grad_target(param):
 # planes, not on the activation-gradient chain, so they run on a second HIP stream and fill those gaps;
 # under stream capture this becomes a fork/join branch of the step's hipGraph.  side_join() makes the
 # current stream wait for them (called by the solvers right after loss.backward()).
-_SIDE = {"enabled": _os.environ.get("ITCV_WGRAD_STREAM", "1") != "0", "stream": None, "dirty": False}
+# Round 2: OFF by default.  With the batched passes the weight-gradient GEMMs fill the chip on their own (one block per
+# CU, the three filter-row blocks of a tile co-located on an XCD), and running them beside the data-gradient chain costs
+# more than the gaps it fills: same-box A/B of the c2 step 18.45 (on) vs 18.0 ms (off).  ITCV_WGRAD_STREAM=1 restores it.
+_SIDE = {"enabled": _os.environ.get("ITCV_WGRAD_STREAM", "0") == "1", "stream": None, "dirty": False}
 
 
 def set_wgrad_stream(flag):
