@@ -219,14 +219,18 @@ int itcv_bn_train_fwd(const float* x, const float* gamma, const float* beta, con
                       int ns, int B, int C, int H, int W, float slope, int pool, float eps, float momentum,
                       float* running_mean, float* running_var, int64_t* num_batches_tracked, float* mean, float* rstd,
                       void* ws, size_t ws_bytes, size_t plane_stride, const float* tile_stats, int tiles, int tile_pitch,
-                      void* stream);
+                      int groups, void* stream);
+/* groups > 1 (itcv_bn_train_fwd / _bwd): x / y / planes (dy / dx / dx_planes) hold `groups` BatchNorm groups of B images
+ * each, stacked along the batch dimension; mean / rstd are [groups][C], dsums [groups][2C]; plane_stride is that of the
+ * whole tensor.  Every group is normalised with its own statistics and advances the running buffers on its own, in
+ * order; small layers do it in one statistics launch + one apply launch for all groups. */
 /* tile_stats (may be NULL): per-tile sums of x written by the producing conv (itcv_conv2d_fwd_bf16p_st):
  * sum at tile_stats[c*tile_pitch + t], sum of squares at tile_stats[(C + c)*tile_pitch + t], t < tiles -- the tiles
  * that make up THIS call's B images; the statistics are then folded from them and x is read once (apply) only. */
 int itcv_bn_train_bwd(const float* x, const float* dy, const float* mean, const float* rstd, const float* gamma,
                       const float* beta, const float* skip, double* dsums, float* dx, float* dskip, void* dx_planes,
                       int ns, float* dgamma, float* dbeta, int accumulate, int B, int C, int H, int W, float slope,
-                      int pool, int up2, void* ws, size_t ws_bytes, size_t plane_stride, void* stream);
+                      int pool, int up2, void* ws, size_t ws_bytes, size_t plane_stride, int groups, void* stream);
 
 /* ---- pointwise / resampling ----------------------------------------------------------- */
 int itcv_lrelu_fwd(const float* x, float* y, size_t n, float slope, void* stream);     /* models.py:271 */

@@ -15,6 +15,18 @@ __device__ __forceinline__ uint32_t fdiv(uint32_t a, uint32_t d, int sh) { retur
 
 // ------------------------------------------------------------------ channel moments (fp64)
 // grid (C, splits): block (c, s) reduces its slice of channel c's B*HW values
+// BatchNorm groups stacked in one tensor (see itcv_bn_train_fwd): element / chunk distances between consecutive groups.
+// Zero-initialised = one group.  Apply kernels take the group from blockIdx.z; the fused statistics kernels walk the
+// groups in order inside the block (the running buffers are advanced group by group).
+struct BnGrp {
+  size_t xs;    // x, skip, dx, dskip: elements per group
+  size_t os;    // forward output y: elements per group
+  size_t dys;   // upstream gradient dy: elements per group (depends on pool / up2)
+  size_t ps;    // planes: chunks per group inside one plane
+  int cs;       // mean / rstd: C per group (dsums: 2C)
+  int G;        // groups walked by the fused statistics kernels (0 or 1 = one)
+};
+
 struct BnFinal {   // arguments of the fused single-launch path (splits == 1)
   double count;
   float eps, momentum;
@@ -28,11 +40,13 @@ struct BnFinal {   // arguments of the fused single-launch path (splits == 1)
 template <bool FUSED>
 __global__ __launch_bounds__(kRedThreads) void bn_moments_partial(const float* __restrict__ x,
                                                                   double* __restrict__ part, int B, int C, int HW,
-                                                                  int splits, int hw_shift, BnFinal f) {
+                                                                  int splits, int hw_shift, BnFinal f, BnGrp grp) {
   __shared__ double scratch[kRedThreads / 64];
   const uint32_t c = blockIdx.x, s = blockIdx.y, hw_n = HW, total = (uint32_t)B * hw_n;
   const uint32_t chunk = ((total + splits - 1) / splits + 3) & ~3u;  // multiple of 4: float4 stays aligned
   const uint32_t beg = s * chunk, end = min(beg + chunk, total);
+  const int ngroups = (FUSED && grp.G > 1) ? grp.G : 1;
+ for (int gi = 0; gi < ngroups; ++gi, x += grp.xs, f.mean += grp.cs, f.rstd += grp.cs) {
   double s1 = 0.0, s2 = 0.0;
   if ((HW & 3) == 0) {
 #pragma unroll 4
@@ -70,6 +84,7 @@ __global__ __launch_bounds__(kRedThreads) void bn_moments_partial(const float* _
       part[((size_t)s * 2 + 1) * C + c] = s2;
     }
   }
+ }
 }
 
 // sums[k][c] = sum_s part[s][k][c]   (k in {0,1}), fixed order
@@ -263,7 +278,13 @@ __global__ __launch_bounds__(256) void bn_act_fwd_planes_kernel(
     const float* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ rstd,
     const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ skip,
     float* __restrict__ y, u32x4* __restrict__ planes, int B, int C, int H, int W, float slope, BnStatsIn st,
-    size_t plane_stride) {
+    size_t plane_stride, BnGrp grp) {
+  {
+    const size_t g = blockIdx.z;     // BatchNorm group (gridDim.z = 1 and a zero `grp` otherwise)
+    x += g * grp.xs, planes += g * grp.ps, mean += g * grp.cs, rstd += g * grp.cs;
+    if (skip) skip += g * grp.xs;
+    if (y) y += g * grp.os;
+  }
   __shared__ float s_mean[STATS ? kStatCh : 1], s_rstd[STATS ? kStatCh : 1];
   constexpr int PX = POOL ? 2 : 4;                      // output pixels per thread
   __shared__ u32x4 strips[STRIP ? 4 : 1][STRIP ? 64 * PX : 1];
@@ -463,12 +484,21 @@ __global__ __launch_bounds__(kRedThreads) void bn_bwd_partial_v4(
     const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ mean,
     const float* __restrict__ rstd, const float* __restrict__ gamma, const float* __restrict__ beta,
     const float* __restrict__ skip, double* __restrict__ part, int B, int C, int H, int W, float slope, int splits,
-    int w_shift, int hw_shift, BnBwdFinal f) {
+    int w_shift, int hw_shift, BnBwdFinal f, BnGrp grp) {
   __shared__ double scratch[kRedThreads / 64];
   const uint32_t c = blockIdx.x, s = blockIdx.y, HW = H * W, total = (uint32_t)B * HW;
   const uint32_t chunk = ((total + splits - 1) / splits + 3) & ~3u;
   const uint32_t beg = s * chunk, end = min(beg + chunk, total);
-  const float mu = mean[c], rs = rstd[c], ga = gamma[c], be = beta[c];
+  const float ga = gamma[c], be = beta[c];
+  const int ngroups = (FUSED && grp.G > 1) ? grp.G : 1;
+  float acc_db = 0.f, acc_dg = 0.f;      // parameter gradients add up over the groups (thread 0)
+  if (FUSED && threadIdx.x == 0 && f.accumulate) {
+    if (f.dbeta) acc_db = f.dbeta[c];
+    if (f.dgamma) acc_dg = f.dgamma[c];
+  }
+ for (int gi = 0; gi < ngroups; ++gi, x += grp.xs, dy += grp.dys, mean += grp.cs, rstd += grp.cs, f.dsums += 2 * grp.cs) {
+  if (skip && gi) skip += grp.xs;
+  const float mu = mean[c], rs = rstd[c];
   double s1 = 0.0, s2 = 0.0;
 #pragma unroll 2
   for (uint32_t i = beg + threadIdx.x * 4; i < end; i += kRedThreads * 4) {
@@ -497,12 +527,16 @@ __global__ __launch_bounds__(kRedThreads) void bn_bwd_partial_v4(
     if (FUSED) {
       f.dsums[c] = s1;
       f.dsums[C + c] = s2;
-      if (f.dbeta) f.dbeta[c] = (f.accumulate ? f.dbeta[c] : 0.f) + (float)s1;
-      if (f.dgamma) f.dgamma[c] = (f.accumulate ? f.dgamma[c] : 0.f) + (float)s2;
+      acc_db += (float)s1, acc_dg += (float)s2;
     } else {
       part[((size_t)s * 2 + 0) * C + c] = s1;
       part[((size_t)s * 2 + 1) * C + c] = s2;
     }
+  }
+ }
+  if (FUSED && threadIdx.x == 0) {
+    if (f.dbeta) f.dbeta[c] = acc_db;
+    if (f.dgamma) f.dgamma[c] = acc_dg;
   }
 }
 
@@ -558,7 +592,15 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_planes(
     const float* __restrict__ rstd, const float* __restrict__ gamma, const float* __restrict__ beta,
     const float* __restrict__ skip, const double* __restrict__ dsums, double count, float* __restrict__ dx,
     float* __restrict__ dskip, u32x4* __restrict__ planes, int B, int C, int H, int W, float slope, int w_shift,
-    BnBwdSumsIn sm, size_t plane_stride) {
+    BnBwdSumsIn sm, size_t plane_stride, BnGrp grp) {
+  {
+    const size_t g = blockIdx.z;     // BatchNorm group (gridDim.z = 1 and a zero `grp` otherwise)
+    x += g * grp.xs, dy += g * grp.dys, planes += g * grp.ps, mean += g * grp.cs, rstd += g * grp.cs;
+    if (dsums) dsums += g * 2 * grp.cs;
+    if (skip) skip += g * grp.xs;
+    if (dx) dx += g * grp.xs;
+    if (dskip) dskip += g * grp.xs;
+  }
   __shared__ float s_m1[SUMS ? kStatCh : 1], s_m2[SUMS ? kStatCh : 1];
   __shared__ u32x4 strips[STRIP ? 4 : 1][STRIP ? 64 * 4 : 1];
   const uint32_t HW = H * W, C8 = C >> 3, per_plane = HW / 4, total = (uint32_t)B * C8 * per_plane;
@@ -730,6 +772,15 @@ static inline int bn_strip_mask() {
   return v;
 }
 
+static inline bool bn_merge_groups() {   // ITCV_BN_MERGE_GROUPS=0: one launch per BatchNorm group always (diagnostic)
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("ITCV_BN_MERGE_GROUPS");
+    v = (e && e[0] == '0') ? 0 : 1;
+  }
+  return v != 0;
+}
+
 static inline bool bn_fuse_finalize() {   // ITCV_BN_FUSE=0: always finalise in a separate launch (diagnostic)
   static int v = -1;
   if (v < 0) {
@@ -773,7 +824,7 @@ int itcv_bn_moments(const float* x, double* sums, int B, int C, int HW, void* ws
   ITCV_REQUIRE(ws && ws_bytes >= (size_t)splits * 2 * C * sizeof(double), "itcv_bn_moments(workspace)");
   double* part = static_cast<double*>(ws);
   hipLaunchKernelGGL(bn_moments_partial<false>, dim3(C, splits), dim3(kRedThreads), 0, S(stream), x, part, B, C, HW,
-                     splits, ilog2_exact(HW), BnFinal{});
+                     splits, ilog2_exact(HW), BnFinal{}, BnGrp{});
   ITCV_CHECK_LAUNCH("itcv_bn_moments");
   hipLaunchKernelGGL(combine_partials, dim3(cdiv(2 * C, 256)), dim3(256), 0, S(stream), part, sums, 2 * C, splits);
   ITCV_CHECK_LAUNCH("itcv_bn_moments(combine)");
@@ -790,12 +841,12 @@ int itcv_bn_train_stats(const float* x, int B, int C, int HW, float eps, float m
   if (splits == 1) {
     const BnFinal f{(double)B * HW, eps, momentum, running_mean, running_var, num_batches_tracked, mean, rstd};
     hipLaunchKernelGGL(bn_moments_partial<true>, dim3(C, 1), dim3(kRedThreads), 0, S(stream), x, part, B, C, HW, 1,
-                       ilog2_exact(HW), f);
+                       ilog2_exact(HW), f, BnGrp{});
     ITCV_CHECK_LAUNCH("itcv_bn_train_stats(fused)");
     return 0;
   }
   hipLaunchKernelGGL(bn_moments_partial<false>, dim3(C, splits), dim3(kRedThreads), 0, S(stream), x, part, B, C, HW,
-                     splits, ilog2_exact(HW), BnFinal{});
+                     splits, ilog2_exact(HW), BnFinal{}, BnGrp{});
   ITCV_CHECK_LAUNCH("itcv_bn_train_stats");
   hipLaunchKernelGGL(bn_combine_finalize_kernel, dim3(cdiv(C, 256)), dim3(256), 0, S(stream), part, splits,
                      (double)B * HW, eps, momentum, running_mean, running_var, num_batches_tracked, mean, rstd, C);
@@ -841,10 +892,10 @@ int itcv_bn_act_fwd(const float* x, const float* mean, const float* rstd, const 
   do {                                                                                                                \
     if (bn_strip_mask() & 1)                                                                                          \
       hipLaunchKernelGGL((bn_act_fwd_planes_kernel<POOL_, NS_, false, true>), grid, blk, 0, S(stream), x, mean, rstd, gamma, \
-                         beta, skip, y, pl, B, C, H, W, slope, BnStatsIn{}, pstride);                                   \
+                         beta, skip, y, pl, B, C, H, W, slope, BnStatsIn{}, pstride, BnGrp{});                                   \
     else                                                                                                              \
       hipLaunchKernelGGL((bn_act_fwd_planes_kernel<POOL_, NS_, false, false>), grid, blk, 0, S(stream), x, mean, rstd, gamma, \
-                         beta, skip, y, pl, B, C, H, W, slope, BnStatsIn{}, pstride);                                   \
+                         beta, skip, y, pl, B, C, H, W, slope, BnStatsIn{}, pstride, BnGrp{});                                   \
   } while (0)
     if (pool) {
       if (ns == 2) ITCV_FWD_PLANES(1, 2);
@@ -891,10 +942,10 @@ int itcv_bn_act_bwd_reduce(const float* x, const float* dy, const float* mean, c
     if (vec && splits == 1)                                                                                      \
       hipLaunchKernelGGL((bn_bwd_partial_v4<MODE, true>), grid, dim3(kRedThreads), 0, st, x, dy, mean, rstd,      \
                          gamma, beta, skip, part, B, C, H, W, slope, 1, wsh, hwsh,                               \
-                         BnBwdFinal{dsums, dgamma, dbeta, accumulate});                                          \
+                         BnBwdFinal{dsums, dgamma, dbeta, accumulate}, BnGrp{});                                          \
     else if (vec)                                                                                                \
       hipLaunchKernelGGL((bn_bwd_partial_v4<MODE, false>), grid, dim3(kRedThreads), 0, st, x, dy, mean, rstd,     \
-                         gamma, beta, skip, part, B, C, H, W, slope, splits, wsh, hwsh, BnBwdFinal{});           \
+                         gamma, beta, skip, part, B, C, H, W, slope, splits, wsh, hwsh, BnBwdFinal{}, BnGrp{});           \
     else                                                                                                         \
       hipLaunchKernelGGL(bn_bwd_partial<MODE>, grid, dim3(kRedThreads), 0, st, x, dy, mean, rstd, gamma, beta,    \
                          skip, part, B, C, H, W, slope, splits);                                                 \
@@ -935,10 +986,10 @@ int itcv_bn_act_bwd_apply(const float* x, const float* dy, const float* mean, co
   do {                                                                                                           \
     if (bn_strip_mask() & ((MODE_) == 0 ? 2 : 4))                                                                \
       hipLaunchKernelGGL((bn_bwd_apply_planes<MODE_, NS_, false, true>), grid, blk, 0, st, x, dy, mean, rstd, gamma, beta, \
-                         skip, dsums, count, dx, dskip, pl, B, C, H, W, slope, wsh, BnBwdSumsIn{}, pstride);       \
+                         skip, dsums, count, dx, dskip, pl, B, C, H, W, slope, wsh, BnBwdSumsIn{}, pstride, BnGrp{});       \
     else                                                                                                         \
       hipLaunchKernelGGL((bn_bwd_apply_planes<MODE_, NS_, false, false>), grid, blk, 0, st, x, dy, mean, rstd, gamma, beta, \
-                         skip, dsums, count, dx, dskip, pl, B, C, H, W, slope, wsh, BnBwdSumsIn{}, pstride);       \
+                         skip, dsums, count, dx, dskip, pl, B, C, H, W, slope, wsh, BnBwdSumsIn{}, pstride, BnGrp{});       \
   } while (0)
 #define ITCV_BWD_PLANES_NS(MODE_)        \
   do {                                   \
@@ -990,8 +1041,57 @@ int itcv_bn_train_fwd(const float* x, const float* gamma, const float* beta, con
                       int ns, int B, int C, int H, int W, float slope, int pool, float eps, float momentum,
                       float* running_mean, float* running_var, int64_t* num_batches_tracked, float* mean, float* rstd,
                       void* ws, size_t ws_bytes, size_t plane_stride, const float* tile_stats, int tiles, int tile_pitch,
-                      void* stream) {
+                      int groups, void* stream) {
   ITCV_REQUIRE(x && gamma && beta && mean && rstd && (y || planes) && B > 0 && C > 0 && H > 0 && W > 0, "itcv_bn_train_fwd");
+  if (groups > 1) {
+    // `groups` BatchNorm groups of B images each, stacked along the batch dimension of x / y / planes; mean / rstd are
+    // [groups][C].  Small layers (one block per channel computes the statistics): ONE statistics launch that walks the
+    // groups in order (the running buffers advance group by group) and ONE apply launch with the group in blockIdx.z.
+    // Other shapes: the groups are issued one after the other.
+    ITCV_REQUIRE(!planes || plane_stride, "itcv_bn_train_fwd(groups need the plane stride of the whole tensor)");
+    const int HWg = H * W, HWo = pool ? HWg / 4 : HWg;
+    const size_t xs = (size_t)B * C * HWg, os = (size_t)B * C * HWo, ps = (size_t)B * (C / 8) * HWo;
+    const bool merged = !tile_stats && bn_splits(B, C, HWg) == 1 && planes && (ns == 2 || ns == 3) &&
+                        itcv_bn_act_planes_supported(C, H, W, pool) && xs < (1ull << 31) && bn_merge_groups();
+    if (!merged) {
+      for (int g = 0; g < groups; ++g)
+        if (int e = itcv_bn_train_fwd(x + g * xs, gamma, beta, skip ? skip + g * xs : nullptr, y ? y + g * os : nullptr,
+                                      planes ? static_cast<u32x4*>(planes) + g * ps : nullptr, ns, B, C, H, W, slope, pool,
+                                      eps, momentum, running_mean, running_var, num_batches_tracked, mean + (size_t)g * C,
+                                      rstd + (size_t)g * C, ws, ws_bytes, plane_stride,
+                                      tile_stats ? tile_stats + (size_t)g * tiles : nullptr, tiles, tile_pitch, 1, stream))
+          return e;
+      return 0;
+    }
+    const BnGrp grp{xs, os, 0, ps, C, groups};
+    const BnFinal f{(double)B * HWg, eps, momentum, running_mean, running_var, num_batches_tracked, mean, rstd};
+    hipLaunchKernelGGL(bn_moments_partial<true>, dim3(C, 1), dim3(kRedThreads), 0, S(stream), x, static_cast<double*>(nullptr),
+                       B, C, HWg, 1, ilog2_exact(HWg), f, grp);
+    ITCV_CHECK_LAUNCH("itcv_bn_train_fwd(grouped statistics)");
+    const size_t threads = (size_t)B * (C / 8) * (HWo / (pool ? 2 : 4));
+    const dim3 grid(grid_for(threads), 1, groups), blk(256);
+    u32x4* pl = static_cast<u32x4*>(planes);
+    const bool strip = bn_strip_mask() & 1;
+#define ITCV_FWD_GRP(POOL_, NS_)                                                                                          \
+  do {                                                                                                                    \
+    if (strip)                                                                                                            \
+      hipLaunchKernelGGL((bn_act_fwd_planes_kernel<POOL_, NS_, false, true>), grid, blk, 0, S(stream), x, mean, rstd, gamma,   \
+                         beta, skip, y, pl, B, C, H, W, slope, BnStatsIn{}, plane_stride, grp);                             \
+    else                                                                                                                  \
+      hipLaunchKernelGGL((bn_act_fwd_planes_kernel<POOL_, NS_, false, false>), grid, blk, 0, S(stream), x, mean, rstd, gamma,  \
+                         beta, skip, y, pl, B, C, H, W, slope, BnStatsIn{}, plane_stride, grp);                             \
+  } while (0)
+    if (pool) {
+      if (ns == 2) ITCV_FWD_GRP(1, 2);
+      else ITCV_FWD_GRP(1, 3);
+    } else {
+      if (ns == 2) ITCV_FWD_GRP(0, 2);
+      else ITCV_FWD_GRP(0, 3);
+    }
+#undef ITCV_FWD_GRP
+    ITCV_CHECK_LAUNCH("itcv_bn_train_fwd(grouped apply)");
+    return 0;
+  }
   const size_t pstride = plane_stride ? plane_stride : (size_t)B * (C / 8) * (pool ? (H / 2) * (W / 2) : H * W);
   if (tile_stats) {   // statistics come from the producing conv's epilogue: fold the tiles, then one apply pass
     ITCV_REQUIRE(tiles > 0 && tile_pitch >= tiles, "itcv_bn_train_fwd(tile statistics)");
@@ -1013,7 +1113,7 @@ int itcv_bn_train_fwd(const float* x, const float* gamma, const float* beta, con
   ITCV_REQUIRE(ws && ws_bytes >= (size_t)splits * 2 * C * sizeof(double), "itcv_bn_train_fwd(workspace)");
   double* part = static_cast<double*>(ws);
   hipLaunchKernelGGL(bn_moments_partial<false>, dim3(C, splits), dim3(kRedThreads), 0, S(stream), x, part, B, C, HW,
-                     splits, ilog2_exact(HW), BnFinal{});
+                     splits, ilog2_exact(HW), BnFinal{}, BnGrp{});
   ITCV_CHECK_LAUNCH("itcv_bn_train_fwd(partials)");
   const BnStatsIn st{part, splits, (double)B * HW, eps, momentum, running_mean, running_var, num_batches_tracked, mean, rstd};
   const size_t threads = (size_t)B * (C / 8) * per_plane;
@@ -1023,10 +1123,10 @@ int itcv_bn_train_fwd(const float* x, const float* gamma, const float* beta, con
   do {                                                                                                                \
     if (bn_strip_mask() & 1)                                                                                          \
       hipLaunchKernelGGL((bn_act_fwd_planes_kernel<POOL_, NS_, true, true>), grid, blk, 0, S(stream), x, mean, rstd, gamma,  \
-                         beta, skip, y, pl, B, C, H, W, slope, st, pstride);                                            \
+                         beta, skip, y, pl, B, C, H, W, slope, st, pstride, BnGrp{});                                            \
     else                                                                                                              \
       hipLaunchKernelGGL((bn_act_fwd_planes_kernel<POOL_, NS_, true, false>), grid, blk, 0, S(stream), x, mean, rstd, gamma, \
-                         beta, skip, y, pl, B, C, H, W, slope, st, pstride);                                            \
+                         beta, skip, y, pl, B, C, H, W, slope, st, pstride, BnGrp{});                                            \
   } while (0)
   if (pool) {
     if (ns == 2) ITCV_FWD_FUSED(1, 2);
@@ -1043,10 +1143,60 @@ int itcv_bn_train_fwd(const float* x, const float* gamma, const float* beta, con
 int itcv_bn_train_bwd(const float* x, const float* dy, const float* mean, const float* rstd, const float* gamma,
                       const float* beta, const float* skip, double* dsums, float* dx, float* dskip, void* dx_planes,
                       int ns, float* dgamma, float* dbeta, int accumulate, int B, int C, int H, int W, float slope,
-                      int pool, int up2, void* ws, size_t ws_bytes, size_t plane_stride, void* stream) {
+                      int pool, int up2, void* ws, size_t ws_bytes, size_t plane_stride, int groups, void* stream) {
   ITCV_REQUIRE(x && dy && mean && rstd && gamma && beta && dsums && (dx || dx_planes) && B > 0 && C > 0,
                "itcv_bn_train_bwd");
   ITCV_REQUIRE(!(pool && up2), "itcv_bn_train_bwd(pool and up2 are exclusive)");
+  if (groups > 1) {   // see itcv_bn_train_fwd; dsums is [groups][2C], the parameter gradients add up over the groups
+    ITCV_REQUIRE(!dx_planes || plane_stride, "itcv_bn_train_bwd(groups need the plane stride of the whole tensor)");
+    const int HWg = H * W;
+    const size_t xs = (size_t)B * C * HWg, dys = pool ? xs / 4 : (up2 ? xs * 4 : xs), ps = (size_t)B * (C / 8) * HWg;
+    const bool vecg = (W % 4 == 0) && xs < (1ull << 31);
+    const bool merged = vecg && bn_splits(B, C, HWg) == 1 && dx_planes && (ns == 2 || ns == 3) &&
+                        itcv_bn_act_planes_supported(C, H, W, 0) && bn_merge_groups();
+    if (!merged) {
+      for (int g = 0; g < groups; ++g)
+        if (int e = itcv_bn_train_bwd(x + g * xs, dy + g * dys, mean + (size_t)g * C, rstd + (size_t)g * C, gamma, beta,
+                                      skip ? skip + g * xs : nullptr, dsums + (size_t)g * 2 * C, dx ? dx + g * xs : nullptr,
+                                      dskip ? dskip + g * xs : nullptr,
+                                      dx_planes ? static_cast<u32x4*>(dx_planes) + g * ps : nullptr, ns, dgamma, dbeta,
+                                      (accumulate || g > 0) ? 1 : 0, B, C, H, W, slope, pool, up2, ws, ws_bytes, plane_stride,
+                                      1, stream))
+          return e;
+      return 0;
+    }
+    if (pool) ITCV_REQUIRE(H % 2 == 0 && W % 2 == 0, "itcv_bn_train_bwd(pool)");
+    const BnGrp grp{xs, 0, dys, ps, C, groups};
+    hipStream_t st = S(stream);
+    const int wsh = ilog2_exact(W), hwsh = ilog2_exact(HWg);
+    const BnBwdFinal bf{dsums, dgamma, dbeta, accumulate};
+    const dim3 rgrid(C, 1), agrid(grid_for(xs / 32), 1, groups), blk(256);
+    u32x4* pl = static_cast<u32x4*>(dx_planes);
+    const double count = (double)B * HWg;
+#define ITCV_BWD_GRP(MODE_, NS_)                                                                                         \
+  do {                                                                                                                   \
+    hipLaunchKernelGGL((bn_bwd_partial_v4<MODE_, true>), rgrid, dim3(kRedThreads), 0, st, x, dy, mean, rstd, gamma, beta,   \
+                       skip, static_cast<double*>(nullptr), B, C, H, W, slope, 1, wsh, hwsh, bf, grp);                   \
+    if (bn_strip_mask() & ((MODE_) == 0 ? 2 : 4))                                                                        \
+      hipLaunchKernelGGL((bn_bwd_apply_planes<MODE_, NS_, false, true>), agrid, blk, 0, st, x, dy, mean, rstd, gamma, beta,  \
+                         skip, dsums, count, dx, dskip, pl, B, C, H, W, slope, wsh, BnBwdSumsIn{}, plane_stride, grp);     \
+    else                                                                                                                 \
+      hipLaunchKernelGGL((bn_bwd_apply_planes<MODE_, NS_, false, false>), agrid, blk, 0, st, x, dy, mean, rstd, gamma, beta, \
+                         skip, dsums, count, dx, dskip, pl, B, C, H, W, slope, wsh, BnBwdSumsIn{}, plane_stride, grp);     \
+  } while (0)
+#define ITCV_BWD_GRP_NS(MODE_)            \
+  do {                                    \
+    if (ns == 2) ITCV_BWD_GRP(MODE_, 2);  \
+    else ITCV_BWD_GRP(MODE_, 3);          \
+  } while (0)
+    if (pool) ITCV_BWD_GRP_NS(1);
+    else if (up2) ITCV_BWD_GRP_NS(2);
+    else ITCV_BWD_GRP_NS(0);
+#undef ITCV_BWD_GRP_NS
+#undef ITCV_BWD_GRP
+    ITCV_CHECK_LAUNCH("itcv_bn_train_bwd(grouped)");
+    return 0;
+  }
   const int HW = H * W, splits = bn_splits(B, C, HW);
   const size_t n = (size_t)B * C * HW;
   const bool vec = (W % 4 == 0) && n < (1ull << 31);
@@ -1072,15 +1222,15 @@ int itcv_bn_train_bwd(const float* x, const float* dy, const float* mean, const 
 #define ITCV_BWD_FUSED(MODE_, NS_)                                                                                    \
   do {                                                                                                                \
     hipLaunchKernelGGL((bn_bwd_partial_v4<MODE_, false>), rgrid, dim3(kRedThreads), 0, st, x, dy, mean, rstd, gamma,   \
-                       beta, skip, part, B, C, H, W, slope, splits, wsh, hwsh, BnBwdFinal{});                         \
+                       beta, skip, part, B, C, H, W, slope, splits, wsh, hwsh, BnBwdFinal{}, BnGrp{});                         \
     if (bn_strip_mask() & ((MODE_) == 0 ? 2 : 4))                                                                     \
       hipLaunchKernelGGL((bn_bwd_apply_planes<MODE_, NS_, true, true>), agrid, blk, 0, st, x, dy, mean, rstd, gamma, beta, \
                          skip, static_cast<const double*>(nullptr), count, dx, dskip, pl, B, C, H, W, slope, wsh, sm,   \
-                         pstride);                                                                                     \
+                         pstride, BnGrp{});                                                                                     \
     else                                                                                                              \
       hipLaunchKernelGGL((bn_bwd_apply_planes<MODE_, NS_, true, false>), agrid, blk, 0, st, x, dy, mean, rstd, gamma, beta, \
                          skip, static_cast<const double*>(nullptr), count, dx, dskip, pl, B, C, H, W, slope, wsh, sm,   \
-                         pstride);                                                                                     \
+                         pstride, BnGrp{});                                                                                     \
   } while (0)
 #define ITCV_BWD_FUSED_NS(MODE_)            \
   do {                                      \

@@ -83,9 +83,9 @@ SIGNATURES = {
     "itcv_bn_act_bwd_apply": (i32, [p, p, p, p, p, p, p, p, p, f64, p, p, p, p, i32, i32, i32, i32, i32, f32,
                                     i32, i32, p, i32, sz, p]),
     "itcv_bn_train_fwd": (i32, [p, p, p, p, p, p, i32, i32, i32, i32, i32, f32, i32, f32, f32, p, p, p, p, p, p, sz, sz, p, i32, i32,
-                                p]),
+                                i32, p]),
     "itcv_bn_train_bwd": (i32, [p, p, p, p, p, p, p, p, p, p, p, i32, p, p, i32, i32, i32, i32, i32, f32, i32, i32, p,
-                                sz, sz, p]),
+                                sz, sz, i32, p]),
     "itcv_lrelu_fwd": (i32, [p, p, sz, f32, p]),
     "itcv_lrelu_bwd": (i32, [p, p, p, sz, f32, p]),
     "itcv_sigmoid_fwd": (i32, [p, p, sz, p]),

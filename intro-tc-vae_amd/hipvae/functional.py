@@ -635,20 +635,19 @@ class BnActFn(Function):
         write_y = out_fp32 or yp is None or _POISON[0]
         nws = lib.itcv_bn_workspace(Bg, C, H * W)
         ts = _tile_stats_of(x, B, G, H * W) if (training and world == 1) else None
-        for g in range(G):
+        if training and world == 1:
+            # statistics + apply for all G groups in one call (small layers: one statistics launch walking the groups in
+            # order + one apply launch; large layers: the groups one after the other inside the library)
+            ws = _ws(nws, dev)
+            call("itcv_bn_train_fwd", ptr(x), ptr(gamma), ptr(beta), ptr(skip), ptr(y) if write_y else None, ptr(yp),
+                 int(out_planes), Bg, C, H, W, float(slope), int(pool), float(eps), float(momentum), ptr(running_mean),
+                 ptr(running_var), ptr(nbt), ptr(mean), ptr(rstd), ptr(ws), nws, pstride,
+                 None if ts is None else ts[0].data_ptr(), ts[1] if ts else 0, ts[2] if ts else 0, G, stream())
+        for g in (range(G) if not (training and world == 1) else ()):
             r = slice(g * Bg, (g + 1) * Bg)
             xg, yg = x[r], (y[r] if write_y else None)
             sg = None if skip is None else skip[r]
             ypg = None if yp is None else yp[g * Bg * (C // 8) * oshape[2] * oshape[3] * 4:]    # int32 elements
-            if training and world == 1:
-                # statistics + apply in one call (the apply launch folds the sliced reduction where it can)
-                ws = _ws(nws, dev)
-                tsp = None if ts is None else ts[0].data_ptr() + 4 * g * ts[1]      # this group's tiles
-                call("itcv_bn_train_fwd", ptr(xg), ptr(gamma), ptr(beta), ptr(sg), ptr(yg), ptr(ypg), int(out_planes), Bg,
-                     C, H, W, float(slope), int(pool), float(eps), float(momentum), ptr(running_mean), ptr(running_var),
-                     ptr(nbt), ptr(mean[g]), ptr(rstd[g]), ptr(ws), nws, pstride, tsp, ts[1] if ts else 0,
-                     ts[2] if ts else 0, stream())
-                continue
             if training:
                 ws = _ws(nws, dev)
                 sums = torch.empty((2 * C,), dtype=torch.float64, device=dev)
@@ -704,7 +703,13 @@ class BnActFn(Function):
             dxp = torch.empty(lib.itcv_planes_bytes(B, C, H * W, grad_planes) // 4, dtype=torch.int32, device=dev)
             pstride = B * (C // 8) * H * W
         write_dx = grad_fp32 or dxp is None or _POISON[0]
-        for g in range(G):
+        if world == 1:
+            ws = _ws(nws, dev)
+            local = torch.empty((G, 2 * C), dtype=torch.float64, device=dev)
+            call("itcv_bn_train_bwd", ptr(x), ptr(dy), ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), ptr(skip), ptr(local),
+                 ptr(dx) if write_dx else None, ptr(dskip), ptr(dxp), grad_planes, ptr(pg), ptr(pb), 1 if direct else 0, Bg,
+                 C, H, W, slope, pool, 0, ptr(ws), nws, pstride, G, stream())
+        for g in (range(G) if world != 1 else ()):
             r = slice(g * Bg, (g + 1) * Bg)
             acc = 1 if (direct or g > 0) else 0       # the groups' parameter gradients add up
             xg, dyg = x[r], dy[r]
@@ -714,18 +719,13 @@ class BnActFn(Function):
             dxpg = None if dxp is None else dxp[g * Bg * (C // 8) * H * W * 4:]
             ws = _ws(nws, dev)
             local = torch.empty((2 * C,), dtype=torch.float64, device=dev)
-            if world == 1:
-                call("itcv_bn_train_bwd", ptr(xg), ptr(dyg), ptr(mean[g]), ptr(rstd[g]), ptr(gamma), ptr(beta), ptr(sg),
-                     ptr(local), ptr(dxg), ptr(dsg), ptr(dxpg), grad_planes, ptr(pg), ptr(pb), acc, Bg, C, H, W,
-                     slope, pool, 0, ptr(ws), nws, pstride, stream())
-            else:
-                call("itcv_bn_act_bwd_reduce", ptr(xg), ptr(dyg), ptr(mean[g]), ptr(rstd[g]), ptr(gamma), ptr(beta), ptr(sg),
-                     ptr(local), ptr(pg), ptr(pb), acc, Bg, C, H, W, slope, pool, 0, ptr(ws), nws, stream())
-                total = local.clone()
-                dist.all_reduce(total, group=group)
-                call("itcv_bn_act_bwd_apply", ptr(xg), ptr(dyg), ptr(mean[g]), ptr(rstd[g]), ptr(gamma), ptr(beta), ptr(sg),
-                     ptr(total), None, float(Bg * H * W * world), ptr(dxg), ptr(dsg), None, None, 0, Bg, C, H, W, slope,
-                     pool, 0, ptr(dxpg), grad_planes, pstride, stream())
+            call("itcv_bn_act_bwd_reduce", ptr(xg), ptr(dyg), ptr(mean[g]), ptr(rstd[g]), ptr(gamma), ptr(beta), ptr(sg),
+                 ptr(local), ptr(pg), ptr(pb), acc, Bg, C, H, W, slope, pool, 0, ptr(ws), nws, stream())
+            total = local.clone()
+            dist.all_reduce(total, group=group)
+            call("itcv_bn_act_bwd_apply", ptr(xg), ptr(dyg), ptr(mean[g]), ptr(rstd[g]), ptr(gamma), ptr(beta), ptr(sg),
+                 ptr(total), None, float(Bg * H * W * world), ptr(dxg), ptr(dsg), None, None, 0, Bg, C, H, W, slope,
+                 pool, 0, ptr(dxpg), grad_planes, pstride, stream())
         if dxp is not None:
             if _POISON[0] and not grad_fp32:
                 dx.fill_(float("nan"))
