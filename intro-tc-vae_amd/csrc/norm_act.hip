@@ -46,6 +46,10 @@ __global__ __launch_bounds__(kRedThreads) void bn_moments_partial(const float* _
   const uint32_t chunk = ((total + splits - 1) / splits + 3) & ~3u;  // multiple of 4: float4 stays aligned
   const uint32_t beg = s * chunk, end = min(beg + chunk, total);
   const int ngroups = (FUSED && grp.G > 1) ? grp.G : 1;
+  if (!FUSED) {   // sliced form: the group comes from blockIdx.z (gridDim.z = 1 and a zero `grp` otherwise)
+    x += (size_t)blockIdx.z * grp.xs;
+    part += (size_t)blockIdx.z * splits * 2 * C;
+  }
  for (int gi = 0; gi < ngroups; ++gi, x += grp.xs, f.mean += grp.cs, f.rstd += grp.cs) {
   double s1 = 0.0, s2 = 0.0;
   if ((HW & 3) == 0) {
@@ -159,6 +163,46 @@ __global__ void bn_combine_finalize_kernel(const double* __restrict__ part, int 
     const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
     running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
   }
+}
+
+// BatchNorm groups, sliced statistics: fold every group's partial sums and finalise the groups IN ORDER (running buffers)
+__global__ void bn_combine_finalize_groups_kernel(const double* __restrict__ part, int splits, int G, double count, float eps,
+                                                  float momentum, float* running_mean, float* running_var, int64_t* nbt,
+                                                  float* mean, float* rstd, int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c == 0 && nbt) nbt[0] += G;
+  if (c >= C) return;
+  for (int g = 0; g < G; ++g) {
+    const double* pg = part + (size_t)g * splits * 2 * C;
+    const double s1 = fold_strided(0.0, pg + c, (size_t)2 * C, splits);
+    const double s2 = fold_strided(0.0, pg + C + c, (size_t)2 * C, splits);
+    const double m = s1 / count;
+    double var = s2 / count - m * m;
+    if (var < 0.0) var = 0.0;
+    mean[(size_t)g * C + c] = (float)m;
+    rstd[(size_t)g * C + c] = (float)(1.0 / sqrt(var + (double)eps));
+    if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)m;
+    if (running_var) {
+      const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+      running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+    }
+  }
+}
+__global__ void bn_combine_param_groups_kernel(const double* __restrict__ part, double* __restrict__ dsums, int C, int splits,
+                                               int G, float* dgamma, float* dbeta, int accumulate) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float db = (accumulate && dbeta) ? dbeta[c] : 0.f, dg = (accumulate && dgamma) ? dgamma[c] : 0.f;
+  for (int g = 0; g < G; ++g) {
+    const double* pg = part + (size_t)g * splits * 2 * C;
+    const double s1 = fold_strided(0.0, pg + c, (size_t)2 * C, splits);
+    const double s2 = fold_strided(0.0, pg + C + c, (size_t)2 * C, splits);
+    dsums[(size_t)g * 2 * C + c] = s1;
+    dsums[(size_t)g * 2 * C + C + c] = s2;
+    db += (float)s1, dg += (float)s2;
+  }
+  if (dbeta) dbeta[c] = db;
+  if (dgamma) dgamma[c] = dg;
 }
 
 // backward: fold the partial sums into dsums and (optionally) the parameter gradients
@@ -491,6 +535,11 @@ __global__ __launch_bounds__(kRedThreads) void bn_bwd_partial_v4(
   const uint32_t beg = s * chunk, end = min(beg + chunk, total);
   const float ga = gamma[c], be = beta[c];
   const int ngroups = (FUSED && grp.G > 1) ? grp.G : 1;
+  if (!FUSED) {   // sliced form: the group comes from blockIdx.z
+    const size_t g = blockIdx.z;
+    x += g * grp.xs, dy += g * grp.dys, mean += g * grp.cs, rstd += g * grp.cs, part += g * splits * 2 * C;
+    if (skip) skip += g * grp.xs;
+  }
   float acc_db = 0.f, acc_dg = 0.f;      // parameter gradients add up over the groups (thread 0)
   if (FUSED && threadIdx.x == 0 && f.accumulate) {
     if (f.dbeta) acc_db = f.dbeta[c];
@@ -1051,8 +1100,45 @@ int itcv_bn_train_fwd(const float* x, const float* gamma, const float* beta, con
     ITCV_REQUIRE(!planes || plane_stride, "itcv_bn_train_fwd(groups need the plane stride of the whole tensor)");
     const int HWg = H * W, HWo = pool ? HWg / 4 : HWg;
     const size_t xs = (size_t)B * C * HWg, os = (size_t)B * C * HWo, ps = (size_t)B * (C / 8) * HWo;
-    const bool merged = !tile_stats && bn_splits(B, C, HWg) == 1 && planes && (ns == 2 || ns == 3) &&
-                        itcv_bn_act_planes_supported(C, H, W, pool) && xs < (1ull << 31) && bn_merge_groups();
+    const int gsplits = bn_splits(B, C, HWg);
+    const bool mergeable = !tile_stats && planes && (ns == 2 || ns == 3) && itcv_bn_act_planes_supported(C, H, W, pool) &&
+                           xs < (1ull << 31) && bn_merge_groups();
+    const bool merged = mergeable && gsplits == 1;
+    if (mergeable && gsplits > 1 && ws && ws_bytes >= (size_t)groups * gsplits * 2 * C * sizeof(double)) {
+      // large layers: sliced statistics of all groups in one launch (group = blockIdx.z), a fold that finalises the groups
+      // in order, one apply launch for all groups
+      const BnGrp grp{xs, os, 0, ps, C, groups};
+      double* part = static_cast<double*>(ws);
+      hipLaunchKernelGGL(bn_moments_partial<false>, dim3(C, gsplits, groups), dim3(kRedThreads), 0, S(stream), x, part, B, C,
+                         HWg, gsplits, ilog2_exact(HWg), BnFinal{}, grp);
+      ITCV_CHECK_LAUNCH("itcv_bn_train_fwd(grouped partials)");
+      hipLaunchKernelGGL(bn_combine_finalize_groups_kernel, dim3(cdiv(C, 256)), dim3(256), 0, S(stream), part, gsplits, groups,
+                         (double)B * HWg, eps, momentum, running_mean, running_var, num_batches_tracked, mean, rstd, C);
+      ITCV_CHECK_LAUNCH("itcv_bn_train_fwd(grouped finalize)");
+      const size_t threads = (size_t)B * (C / 8) * (HWo / (pool ? 2 : 4));
+      const dim3 grid(grid_for(threads), 1, groups), blk(256);
+      u32x4* pl = static_cast<u32x4*>(planes);
+      const bool strip = bn_strip_mask() & 1;
+#define ITCV_FWD_GRP2(POOL_, NS_)                                                                                         \
+  do {                                                                                                                    \
+    if (strip)                                                                                                            \
+      hipLaunchKernelGGL((bn_act_fwd_planes_kernel<POOL_, NS_, false, true>), grid, blk, 0, S(stream), x, mean, rstd, gamma,   \
+                         beta, skip, y, pl, B, C, H, W, slope, BnStatsIn{}, plane_stride, grp);                             \
+    else                                                                                                                  \
+      hipLaunchKernelGGL((bn_act_fwd_planes_kernel<POOL_, NS_, false, false>), grid, blk, 0, S(stream), x, mean, rstd, gamma,  \
+                         beta, skip, y, pl, B, C, H, W, slope, BnStatsIn{}, plane_stride, grp);                             \
+  } while (0)
+      if (pool) {
+        if (ns == 2) ITCV_FWD_GRP2(1, 2);
+        else ITCV_FWD_GRP2(1, 3);
+      } else {
+        if (ns == 2) ITCV_FWD_GRP2(0, 2);
+        else ITCV_FWD_GRP2(0, 3);
+      }
+#undef ITCV_FWD_GRP2
+      ITCV_CHECK_LAUNCH("itcv_bn_train_fwd(grouped apply)");
+      return 0;
+    }
     if (!merged) {
       for (int g = 0; g < groups; ++g)
         if (int e = itcv_bn_train_fwd(x + g * xs, gamma, beta, skip ? skip + g * xs : nullptr, y ? y + g * os : nullptr,
@@ -1152,8 +1238,45 @@ int itcv_bn_train_bwd(const float* x, const float* dy, const float* mean, const 
     const int HWg = H * W;
     const size_t xs = (size_t)B * C * HWg, dys = pool ? xs / 4 : (up2 ? xs * 4 : xs), ps = (size_t)B * (C / 8) * HWg;
     const bool vecg = (W % 4 == 0) && xs < (1ull << 31);
-    const bool merged = vecg && bn_splits(B, C, HWg) == 1 && dx_planes && (ns == 2 || ns == 3) &&
-                        itcv_bn_act_planes_supported(C, H, W, 0) && bn_merge_groups();
+    const int gsplits = bn_splits(B, C, HWg);
+    const bool mergeable = vecg && dx_planes && (ns == 2 || ns == 3) && itcv_bn_act_planes_supported(C, H, W, 0) &&
+                           bn_merge_groups();
+    const bool merged = mergeable && gsplits == 1;
+    if (mergeable && gsplits > 1 && ws && ws_bytes >= (size_t)groups * gsplits * 2 * C * sizeof(double)) {
+      if (pool) ITCV_REQUIRE(H % 2 == 0 && W % 2 == 0, "itcv_bn_train_bwd(pool)");
+      const BnGrp grp{xs, 0, dys, ps, C, groups};
+      hipStream_t st = S(stream);
+      const int wsh = ilog2_exact(W), hwsh = ilog2_exact(HWg);
+      double* part = static_cast<double*>(ws);
+      const dim3 rgrid(C, gsplits, groups), agrid(grid_for(xs / 32), 1, groups), blk(256);
+      u32x4* pl = static_cast<u32x4*>(dx_planes);
+      const double count = (double)B * HWg;
+#define ITCV_BWD_GRP2(MODE_, NS_)                                                                                        \
+  do {                                                                                                                   \
+    hipLaunchKernelGGL((bn_bwd_partial_v4<MODE_, false>), rgrid, dim3(kRedThreads), 0, st, x, dy, mean, rstd, gamma, beta,  \
+                       skip, part, B, C, H, W, slope, gsplits, wsh, hwsh, BnBwdFinal{}, grp);                            \
+    hipLaunchKernelGGL(bn_combine_param_groups_kernel, dim3(cdiv(C, 256)), dim3(256), 0, st, part, dsums, C, gsplits,     \
+                       groups, dgamma, dbeta, accumulate);                                                               \
+    if (bn_strip_mask() & ((MODE_) == 0 ? 2 : 4))                                                                        \
+      hipLaunchKernelGGL((bn_bwd_apply_planes<MODE_, NS_, false, true>), agrid, blk, 0, st, x, dy, mean, rstd, gamma, beta,  \
+                         skip, dsums, count, dx, dskip, pl, B, C, H, W, slope, wsh, BnBwdSumsIn{}, plane_stride, grp);     \
+    else                                                                                                                 \
+      hipLaunchKernelGGL((bn_bwd_apply_planes<MODE_, NS_, false, false>), agrid, blk, 0, st, x, dy, mean, rstd, gamma, beta, \
+                         skip, dsums, count, dx, dskip, pl, B, C, H, W, slope, wsh, BnBwdSumsIn{}, plane_stride, grp);     \
+  } while (0)
+#define ITCV_BWD_GRP2_NS(MODE_)            \
+  do {                                     \
+    if (ns == 2) ITCV_BWD_GRP2(MODE_, 2);  \
+    else ITCV_BWD_GRP2(MODE_, 3);          \
+  } while (0)
+      if (pool) ITCV_BWD_GRP2_NS(1);
+      else if (up2) ITCV_BWD_GRP2_NS(2);
+      else ITCV_BWD_GRP2_NS(0);
+#undef ITCV_BWD_GRP2_NS
+#undef ITCV_BWD_GRP2
+      ITCV_CHECK_LAUNCH("itcv_bn_train_bwd(grouped, sliced)");
+      return 0;
+    }
     if (!merged) {
       for (int g = 0; g < groups; ++g)
         if (int e = itcv_bn_train_bwd(x + g * xs, dy + g * dys, mean + (size_t)g * C, rstd + (size_t)g * C, gamma, beta,

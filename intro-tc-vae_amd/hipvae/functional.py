@@ -633,7 +633,7 @@ class BnActFn(Function):
                              device=dev)
             pstride = B * (C // 8) * oshape[2] * oshape[3]            # chunks between planes of the WHOLE tensor
         write_y = out_fp32 or yp is None or _POISON[0]
-        nws = lib.itcv_bn_workspace(Bg, C, H * W)
+        nws = lib.itcv_bn_workspace(Bg, C, H * W) * G      # every group's partial sums (one launch for all groups)
         ts = _tile_stats_of(x, B, G, H * W) if (training and world == 1) else None
         if training and world == 1:
             # statistics + apply for all G groups in one call (small layers: one statistics launch walking the groups in
@@ -683,7 +683,7 @@ class BnActFn(Function):
         dy = _f32c(dy)
         dev = x.device
         Bg = B // G
-        nws = lib.itcv_bn_workspace(Bg, C, H * W)
+        nws = lib.itcv_bn_workspace(Bg, C, H * W) * G
         # parameter gradients come out of the reduce launch: either added straight into .grad
         # (solver mode) or into fresh tensors handed to autograd
         tg = _grad_target(gamma) if ctx.needs_input_grad[1] else None

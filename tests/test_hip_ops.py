@@ -411,11 +411,12 @@ def test_errors_are_loud():
 
 @pytest.mark.parametrize("pool", [False, True])
 @pytest.mark.parametrize("planes", [0, 2])
-def test_bn_groups_equal_separate_passes(HF, pool, planes):
+@pytest.mark.parametrize("dims", [(2, 6, 16, 8, 8), (2, 8, 32, 32, 32), (3, 4, 64, 16, 16)])
+def test_bn_groups_equal_separate_passes(HF, pool, planes, dims):
     """BatchNorm groups (models.bn_groups): one call on G stacked passes == G separate calls -- outputs, the planes
     handed to the consumer conv, running buffers (advanced once per pass, in order), and every gradient, bit for bit
     (the same kernels run on the same sub-batches)."""
-    G, Bg, C, H, W = 2, 6, 16, 8, 8
+    G, Bg, C, H, W = dims      # one-block-per-channel statistics (first) and sliced statistics (the other two)
     g = torch.Generator().manual_seed(31)
     d = dev()
     x = (torch.randn(G * Bg, C, H, W, generator=g) * 1.5 + 0.3).to(d)
