@@ -176,8 +176,12 @@ class VAESolver:
             torch.cuda.synchronize()
             ent["graph"] = torch.cuda.CUDAGraph()
             # thread-local capture mode: the input pipeline's staging thread (hipvae.loader) may allocate pinned memory or
-            # issue copies on its own stream while this thread captures
-            with torch.cuda.graph(ent["graph"], capture_error_mode="thread_local"):
+            # issue copies on its own stream while this thread captures.  Data-parallel capture keeps the default (global)
+            # mode: RCCL's watchdog thread relies on it to leave the events of captured collectives alone (in thread-local
+            # mode it queried one and aborted the process: "operation not permitted on an event last recorded in a
+            # capturing stream").
+            mode = "thread_local" if ddp.get() is None else "global"
+            with torch.cuda.graph(ent["graph"], capture_error_mode=mode):
                 ent["out"] = self._device_step(ent["inp"])
             graphs[key] = ent
         self._graph, self._graph_key, self._graph_in, self._graph_out = ent["graph"], key, ent["inp"], ent["out"]
