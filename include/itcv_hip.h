@@ -135,6 +135,12 @@ int itcv_conv2d_small_cout_fwd(const float* x, const float* w, const float* bias
 int itcv_conv2d_small_cin_supported(int C, int KS);
 int itcv_conv2d_small_cin_fwd(const float* x, const float* w, const float* bias, float* y, int B, int C, int H,
                               int W, int Co, int KS, int for_dgrad, void* stream);
+
+/* The same conv for C <= 3, Co == 64, KS == 5, W % 32 == 0 (the stem layer models.py:199-204 and the data-gradient of
+ * the prediction layer models.py:271) as split-bf16 (bf16x3) products on the matrix cores. */
+int itcv_conv2d_small_cin_bf16x3_supported(int C, int Co, int KS, int W);
+int itcv_conv2d_small_cin_fwd_bf16x3(const float* x, const float* w, const float* bias, float* y, int B, int C, int H,
+                                     int W, int Co, int KS, int for_dgrad, void* stream);
 /* Split-bf16 weight gradient (same arithmetic, same workspace size as itcv_conv2d_wgrad_workspace):
  * needs KS in {1,3}, Ci % 32 == 0, W % 8 == 0, Co > 32 and a materialised (not virtually upsampled) x. */
 int itcv_conv2d_wgrad_bf16s_supported(int Ci, int H, int W, int Co, int KS);

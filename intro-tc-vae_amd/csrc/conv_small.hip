@@ -8,6 +8,8 @@
 // operands (s_load) -- 3 FMAs per LDS read.  fp32 throughout (exact, like the fp32 MFMA path).
 #include "common.h"
 
+#include <algorithm>
+
 namespace itcv {
 
 constexpr int kTile = 16, kChunk = 8;
@@ -232,6 +234,117 @@ __global__ __launch_bounds__(256) void conv_small_cout_planes_kernel(const u32x4
   }
 }
 
+// ---- <= 3 reduction channels, 64 outputs, 5x5, on the bf16 matrix cores (bf16x3) ----------------------------------
+// The stem layer (image -> 64 channels) and the data-gradient of the 64 -> 3 prediction layer.  MFMA rows are the 64
+// output channels, columns 32 pixels of an image row, and the reduction index of one 32x32x16 product is (dw, ci) --
+// 5*CI <= 15 of 16 slots -- for ONE filter row dh; the five filter rows accumulate into the same tile.  A lane's B
+// fragment of an input row is 8 fp32 pixels read straight from the image (column n + dw - 2 of channel ci), split into
+// two bf16 planes once and kept for the five output rows that touch it (a ring of five fragments while the wave walks
+// down its strip), the weights (5 x 2 x 2 fragments) stay in registers: per output row a wave issues 8 loads,
+// 30 MFMAs and 32 128-byte store segments.
+typedef float f32x16_t __attribute__((ext_vector_type(16)));
+
+template <int CI, bool DGRAD>
+__global__ __launch_bounds__(256, 2) void conv_small_cin_mfma_kernel(const float* __restrict__ x,
+                                                                 const float* __restrict__ w,
+                                                                 const float* __restrict__ bias, float* __restrict__ y,
+                                                                 int H, int W, int strips, int row_blocks, int RB,
+                                                                 int njobs) {
+  constexpr int KS = 5, KK = 25, M = 64;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int job = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + wv);   // wave-uniform: addresses go to SGPRs
+  if (job >= njobs) return;
+  const int s = job % strips, rbk = (job / strips) % row_blocks, b = job / (strips * row_blocks);
+  const int n = lane & 31, kg = lane >> 5;
+  const int h0 = rbk * RB, w0 = s * 32;
+  const int nrows = min(RB, H - h0);
+  const size_t HW = (size_t)H * W;
+
+  // this lane's 8 reduction slots k = 8*kg + j -> (dw, ci); slots >= 5*CI are padding
+  int k_dw[8], k_ci[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int k = kg * 8 + j;
+    k_dw[j] = k / CI;
+    k_ci[j] = k - k_dw[j] * CI;
+  }
+  // A fragments: row m = output channel (mt*32 + n), two bf16 planes, per filter row dh
+  bf16x8 af[5][2][2];
+#pragma unroll
+  for (int dh = 0; dh < 5; ++dh)
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+      const int m = mt * 32 + n;
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int tap = dh * KS + k_dw[j];
+        float t = 0.f;
+        if (k_dw[j] < KS)
+          t = DGRAD ? w[((size_t)k_ci[j] * M + m) * KK + (KK - 1 - tap)] : w[((size_t)m * CI + k_ci[j]) * KK + tap];
+        v[j] = t;
+      }
+      u32x4 pl[2];
+      split8<2>(v, pl);
+      af[dh][mt][0] = __builtin_bit_cast(bf16x8, pl[0]);
+      af[dh][mt][1] = __builtin_bit_cast(bf16x8, pl[1]);
+    }
+  const float* xb = x + (size_t)b * CI * HW;
+  // element offset of slot j inside the image at row 0 (row-independent), -1 = padding slot or column outside
+  int offj[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int col = w0 + n + k_dw[j] - 2;
+    offj[j] = (k_dw[j] < KS && (unsigned)col < (unsigned)W) ? k_ci[j] * (int)HW + col : -1;
+  }
+  auto load_row = [&](int hr, u32x4 (&dst)[2]) {
+    float v[8];
+    const bool rok = (unsigned)hr < (unsigned)H;
+    const float* xr = xb + hr * W;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = (rok && offj[j] >= 0) ? xr[offj[j]] : 0.f;
+    split8<2>(v, dst);
+  };
+  // ring of input-row fragments: slot q holds input row h0 - 2 + i with i % 5 == q
+  u32x4 ring[5][2];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) load_row(h0 - 2 + q, ring[q]);
+  float* yb = y + (size_t)b * M * HW;            // uniform
+  const int lane_off = 4 * kg * (int)HW + w0 + n;
+  for (int o0 = 0; o0 < nrows; o0 += 5) {
+#pragma unroll
+    for (int u = 0; u < 5; ++u) {
+      const int o = o0 + u;                      // output row h0 + o needs input rows i = o .. o + 4
+      if (o >= nrows) break;
+      load_row(h0 + o + 2, ring[(u + 4) % 5]);
+      f32x16_t acc[2];
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mt][r] = 0.f;
+#pragma unroll
+      for (int dh = 0; dh < 5; ++dh) {
+        const bf16x8 b0 = __builtin_bit_cast(bf16x8, ring[(u + dh) % 5][0]),
+                     b1 = __builtin_bit_cast(bf16x8, ring[(u + dh) % 5][1]);
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+          acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[dh][mt][0], b1, acc[mt], 0, 0, 0);
+          acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[dh][mt][1], b0, acc[mt], 0, 0, 0);
+          acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[dh][mt][0], b0, acc[mt], 0, 0, 0);
+        }
+      }
+      float* yr = yb + (size_t)(h0 + o) * W;
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int mu = mt * 32 + (r & 3) + 8 * (r >> 2);   // + 4*kg inside lane_off
+          yr[(size_t)mu * HW + lane_off] = acc[mt][r] + (bias ? bias[mu + 4 * kg] : 0.f);
+        }
+    }
+  }
+}
+
 }  // namespace itcv
 
 using namespace itcv;
@@ -344,6 +457,44 @@ int itcv_conv2d_small_cin_fwd(const float* x, const float* w, const float* bias,
 #undef ITCV_SCIN_KS
 #undef ITCV_SCIN
   ITCV_CHECK_LAUNCH("itcv_conv2d_small_cin_fwd");
+  return 0;
+}
+
+// bf16x3 form of the <= 3-channel -> 64-channel 5x5 conv (itcv_conv2d_small_cin_fwd's hot case) on the matrix cores;
+// same tensors and for_dgrad meaning, results equal up to the 2^-16-per-product rounding of the split.
+int itcv_conv2d_small_cin_bf16x3_supported(int C, int Co, int KS, int W) {
+  return C >= 1 && C <= 3 && Co == 64 && KS == 5 && W >= 32 && W % 32 == 0;
+}
+
+int itcv_conv2d_small_cin_fwd_bf16x3(const float* x, const float* w, const float* bias, float* y, int B, int C, int H,
+                                     int W, int Co, int KS, int for_dgrad, void* stream) {
+  ITCV_REQUIRE(x && w && y && B > 0 && H > 0 && W > 0, "itcv_conv2d_small_cin_fwd_bf16x3");
+  if (!itcv_conv2d_small_cin_bf16x3_supported(C, Co, KS, W))
+    return fail("%s: needs C <= 3, Co == 64, KS == 5, W %% 32 == 0", "itcv_conv2d_small_cin_fwd_bf16x3");
+  const int strips = W / 32;
+  // >= 2048 wave jobs where the image allows it (one wave per SIMD on 256 CUs, two rounds), >= 8 rows per job so the
+  // 4-row halo stays a small part of the reads
+  int row_blocks = cdiv(2048, B * strips);
+  row_blocks = std::max(1, std::min(row_blocks, std::max(1, H / 8)));
+  const int RB = cdiv(H, row_blocks);
+  row_blocks = cdiv(H, RB);
+  const int njobs = B * row_blocks * strips;
+  hipStream_t st = S(stream);
+  ProfScope prof(st, 5, KS, C, 0, 2, 2.0 * B * H * W * (double)Co * C * KS * KS);
+#define ITCV_SCIN_M(CI_)                                                                                              \
+  do {                                                                                                                \
+    if (for_dgrad)                                                                                                    \
+      launch_timed((conv_small_cin_mfma_kernel<CI_, true>), dim3(cdiv(njobs, 4)), dim3(256), 0, st, x, w, bias, y, H, \
+                   W, strips, row_blocks, RB, njobs);                                                                 \
+    else                                                                                                              \
+      launch_timed((conv_small_cin_mfma_kernel<CI_, false>), dim3(cdiv(njobs, 4)), dim3(256), 0, st, x, w, bias, y, H, \
+                   W, strips, row_blocks, RB, njobs);                                                                 \
+  } while (0)
+  if (C == 1) ITCV_SCIN_M(1);
+  else if (C == 2) ITCV_SCIN_M(2);
+  else ITCV_SCIN_M(3);
+#undef ITCV_SCIN_M
+  ITCV_CHECK_LAUNCH("itcv_conv2d_small_cin_fwd_bf16x3");
   return 0;
 }
 

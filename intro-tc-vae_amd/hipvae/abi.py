@@ -63,6 +63,8 @@ SIGNATURES = {
     "itcv_conv2d_small_cout_fwd": (i32, [p, p, p, p] + [i32] * 7 + [p]),
     "itcv_conv2d_small_cin_supported": (i32, [i32, i32]),
     "itcv_conv2d_small_cin_fwd": (i32, [p, p, p, p] + [i32] * 7 + [p]),
+    "itcv_conv2d_small_cin_bf16x3_supported": (i32, [i32, i32, i32, i32]),
+    "itcv_conv2d_small_cin_fwd_bf16x3": (i32, [p, p, p, p] + [i32] * 7 + [p]),
     "itcv_conv2d_wgrad_bf16s_supported": (i32, [i32] * 5),
     "itcv_conv2d_wgrad_bf16s": (i32, [p, p, p] + [i32] * 8 + [p, sz, p]),
     "itcv_conv2d_wgrad_workspace": (sz, [i32] * 6),

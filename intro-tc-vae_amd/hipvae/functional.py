@@ -179,6 +179,11 @@ def pack_weight_bf16s(w4, for_dgrad, ns):
     return wp
 
 
+# bf16x3 mode: the 3 -> 64 stem conv and the prediction layer's data-gradient on the matrix cores (ITCV_SCIN_MFMA=0: the
+# direct fp32 kernel, as in the other arithmetic modes)
+_SCIN_MFMA = [_os.environ.get("ITCV_SCIN_MFMA", "1") != "0"]
+
+
 def conv_apply(x, weight, w4, for_dgrad, bias, B, Ci, H, W, Co, KS, up2):
     """Forward-type conv GEMM (forward, or data-gradient with the roles of Ci/Co swapped by the caller)
     on the kernel selected by set_conv_math()."""
@@ -192,6 +197,10 @@ def conv_apply(x, weight, w4, for_dgrad, bias, B, Ci, H, W, Co, KS, up2):
     if not up2 and lib.itcv_conv2d_small_cin_supported(Ci, KS):
         # <= 4 reduction channels: direct fp32 conv, the pixel's input window lives in registers
         y = torch.empty((B, Co, H, W), dtype=F32, device=x.device)
+        if _SCIN_MFMA[0] and _NS[_CONV_MATH[0]] == 2 and lib.itcv_conv2d_small_cin_bf16x3_supported(Ci, Co, KS, W):
+            call("itcv_conv2d_small_cin_fwd_bf16x3", ptr(x), ptr(w4), ptr(bias), ptr(y), B, Ci, H, W, Co, KS,
+                 int(for_dgrad), stream())
+            return y
 
         call("itcv_conv2d_small_cin_fwd", ptr(x), ptr(w4), ptr(bias), ptr(y), B, Ci, H, W, Co, KS, int(for_dgrad),
              stream())

@@ -155,6 +155,37 @@ def test_small_cout_conv_on_planes(HF, B, S, Co, dgrad):
     assert rel_err(got, ref) < 5e-5
 
 
+@pytest.mark.parametrize("B,H,W,Ci,dgrad", [(3, 32, 32, 3, False), (2, 64, 64, 3, True), (5, 20, 64, 2, False),
+                                            (2, 7, 32, 1, True), (1, 128, 128, 3, False), (1, 40, 256, 3, True),
+                                            (64, 64, 64, 3, False)])
+def test_small_cin_conv_on_matrix_cores(HF, B, H, W, Ci, dgrad):
+    """The 5x5, <= 3-channel -> 64-channel conv (stem layer / predict data-gradient) as bf16x3 products on the matrix
+    cores: reduction (dw, ci) per filter row, ring of five input-row fragments -- against fp64 (bf16x3: 5e-5) and the
+    direct fp32 kernel it replaces; ragged row blocks, image edges, bias."""
+    assert HF.lib.itcv_conv2d_small_cin_bf16x3_supported(Ci, 64, 5, W)
+    assert not HF.lib.itcv_conv2d_small_cin_bf16x3_supported(Ci, 64, 5, 48)
+    assert not HF.lib.itcv_conv2d_small_cin_bf16x3_supported(4, 64, 5, W)
+    g = torch.Generator().manual_seed(B * 100 + H + W + Ci)
+    x = torch.randn(B, Ci, H, W, generator=g)
+    w = torch.randn((Ci, 64, 5, 5) if dgrad else (64, Ci, 5, 5), generator=g) / 6.0
+    bias = None if dgrad else torch.randn(64, generator=g)
+    wr = (w.flip(2, 3).transpose(0, 1) if dgrad else w).double()
+    ref = F.conv2d(x.double(), wr, None if bias is None else bias.double(), padding=2)
+    xd, wd, bd = x.to(dev()), w.to(dev()), None if bias is None else bias.to(dev())
+    prev = HF._CONV_MATH[0]
+    try:
+        HF.set_conv_math("bf16x3")
+        got = HF.conv_apply(xd, wd, wd, int(dgrad), bd, B, Ci, H, W, 64, 5, False)
+        HF._SCIN_MFMA[0] = False
+        direct = HF.conv_apply(xd, wd, wd, int(dgrad), bd, B, Ci, H, W, 64, 5, False)
+    finally:
+        HF._SCIN_MFMA[0] = True
+        HF.set_conv_math(prev)
+    assert rel_err(direct, ref) < 1e-5
+    assert rel_err(got, ref) < 5e-5
+    assert not torch.equal(got, direct)      # really the other kernel
+
+
 @pytest.mark.parametrize("B,S,Cs,stem", [(3, 32, 3, True), (2, 64, 3, False), (5, 32, 2, False), (2, 64, 1, True),
                                           (1, 128, 3, True), (1, 128, 3, False), (1, 256, 3, True)])
 def test_wgrad5_on_planes(HF, B, S, Cs, stem):
