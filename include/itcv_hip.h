@@ -71,6 +71,14 @@ int itcv_conv2d_bf16s_supported(int Ci, int Co, int KS);
 size_t itcv_conv2d_packed_weight_bytes_bf16s(int Co, int Ci, int KS, int for_dgrad, int ns);
 int itcv_conv2d_pack_weight_bf16s(const float* w, void* wp, int Co, int Ci, int KS, int for_dgrad, int ns,
                                   void* stream);
+/* The same packing for many layers in ONE launch (the conv weights of a network after its optimiser step,
+ * solvers/intro.py:116,160, solvers/vae.py:109-110): the caller fills a host array of n descriptors of itcv_pack_desc_bytes() each with
+ * itcv_conv2d_pack_desc_bf16s (returns the number of blocks the layer adds, or a negative error; block0 = the running
+ * sum of those), copies it to the device once and launches itcv_conv2d_pack_weights_bf16s with the total. */
+size_t itcv_pack_desc_bytes(void);
+int itcv_conv2d_pack_desc_bf16s(void* host_desc, const float* w, void* wp, int Co, int Ci, int KS, int for_dgrad,
+                                int ns, int block0);
+int itcv_conv2d_pack_weights_bf16s(const void* dev_table, int n, int total_blocks, int ns, void* stream);
 size_t itcv_conv2d_fwd_bf16s_workspace(int B, int Ci, int H, int W, int Co, int KS);
 int itcv_conv2d_fwd_bf16s(const float* x, const void* wp, const float* bias, float* y, int B, int Ci, int H,
                           int W, int Co, int KS, int up2, int ns, void* ws, size_t ws_bytes, void* stream);

@@ -989,10 +989,10 @@ __global__ void split_planes_kernel(const float* __restrict__ x, u32x4* __restri
 
 // wp[kt = cib*KK + tap][plane][kc][Mp] 16-byte chunks of 8 bf16: channels cib*32 + kc*8 + j
 template <int NS>
-__global__ void pack_weight_bf16s_kernel(const float* __restrict__ w, u32x4* __restrict__ wp, int Co, int Ci, int KK,
-                                         int for_dgrad, int C, int M, int cpt, int Mp) {
+__device__ __forceinline__ void pack_weight_bf16s_body(const float* __restrict__ w, u32x4* __restrict__ wp, int Ci, int KK,
+                                                       int for_dgrad, int C, int M, int cpt, int Mp, int blk, int nblk) {
   const size_t total = (size_t)KK * cpt * 4 * Mp;   // one thread per (kt, kc, m)
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+  for (size_t i = (size_t)blk * blockDim.x + threadIdx.x; i < total; i += (size_t)nblk * blockDim.x) {
     const int m = (int)(i % Mp);
     const size_t r = i / Mp;
     const int kc = (int)(r & 3), kt = (int)(r >> 2);
@@ -1010,6 +1010,30 @@ __global__ void pack_weight_bf16s_kernel(const float* __restrict__ w, u32x4* __r
 #pragma unroll
     for (int p = 0; p < NS; ++p) wp[(((size_t)kt * NS + p) * 4 + kc) * Mp + m] = pl[p];
   }
+}
+
+template <int NS>
+__global__ void pack_weight_bf16s_kernel(const float* __restrict__ w, u32x4* __restrict__ wp, int Co, int Ci, int KK,
+                                         int for_dgrad, int C, int M, int cpt, int Mp) {
+  pack_weight_bf16s_body<NS>(w, wp, Ci, KK, for_dgrad, C, M, cpt, Mp, blockIdx.x, gridDim.x);
+}
+
+// Many layers in one launch: a device-resident table of descriptors, every layer owns a contiguous block range.
+struct PackDesc {
+  const float* w;
+  u32x4* wp;
+  int Ci, KK, for_dgrad, C, M, cpt, Mp;
+  int block0, nblocks;
+  int pad_;
+};
+static_assert(sizeof(PackDesc) == 56, "PackDesc layout is part of the ABI (itcv_pack_desc_bytes)");
+
+template <int NS>
+__global__ void pack_weights_bf16s_table_kernel(const PackDesc* __restrict__ tab, int n) {
+  int e = 0;
+  while (e + 1 < n && (int)blockIdx.x >= tab[e + 1].block0) ++e;
+  const PackDesc d = tab[e];
+  pack_weight_bf16s_body<NS>(d.w, d.wp, d.Ci, d.KK, d.for_dgrad, d.C, d.M, d.cpt, d.Mp, blockIdx.x - d.block0, d.nblocks);
 }
 
 // ------------------------------------------------------------------------------ wgrad
@@ -2259,6 +2283,36 @@ int itcv_conv2d_pack_weight_bf16s(const float* w, void* wp, int Co, int Ci, int 
     hipLaunchKernelGGL(pack_weight_bf16s_kernel<3>, dim3(blocks), dim3(256), 0, S(stream), w, static_cast<u32x4*>(wp),
                        Co, Ci, KS * KS, for_dgrad, C, M, cpt, Mp);
   ITCV_CHECK_LAUNCH("itcv_conv2d_pack_weight_bf16s");
+  return 0;
+}
+
+size_t itcv_pack_desc_bytes(void) { return sizeof(PackDesc); }
+
+int itcv_conv2d_pack_desc_bf16s(void* host_desc, const float* w, void* wp, int Co, int Ci, int KS, int for_dgrad,
+                                int ns, int block0) {
+  ITCV_REQUIRE(host_desc && w && wp && Co > 0 && Ci > 0 && (KS == 1 || KS == 3) && (ns == 2 || ns == 3) && block0 >= 0,
+               "itcv_conv2d_pack_desc_bf16s");
+  const int M = for_dgrad ? Ci : Co, C = for_dgrad ? Co : Ci;
+  const int bm = M <= 64 ? 64 : 128, Mp = cdiv(M, bm) * bm, cpt = pad32(C) / 32;
+  const size_t total = (size_t)KS * KS * cpt * 4 * Mp;
+  PackDesc d;
+  memset(&d, 0, sizeof(d));
+  d.w = w, d.wp = static_cast<u32x4*>(wp);
+  d.Ci = Ci, d.KK = KS * KS, d.for_dgrad = for_dgrad, d.C = C, d.M = M, d.cpt = cpt, d.Mp = Mp;
+  d.block0 = block0;
+  d.nblocks = (int)(cdivz(total, 256) < 1024 ? cdivz(total, 256) : 1024);
+  memcpy(host_desc, &d, sizeof(d));
+  return d.nblocks;      // > 0: the number of blocks this layer adds to the launch
+}
+
+int itcv_conv2d_pack_weights_bf16s(const void* dev_table, int n, int total_blocks, int ns, void* stream) {
+  ITCV_REQUIRE(dev_table && n > 0 && total_blocks > 0 && (ns == 2 || ns == 3), "itcv_conv2d_pack_weights_bf16s");
+  const PackDesc* tab = static_cast<const PackDesc*>(dev_table);
+  if (ns == 2)
+    hipLaunchKernelGGL(pack_weights_bf16s_table_kernel<2>, dim3(total_blocks), dim3(256), 0, S(stream), tab, n);
+  else
+    hipLaunchKernelGGL(pack_weights_bf16s_table_kernel<3>, dim3(total_blocks), dim3(256), 0, S(stream), tab, n);
+  ITCV_CHECK_LAUNCH("itcv_conv2d_pack_weights_bf16s");
   return 0;
 }
 

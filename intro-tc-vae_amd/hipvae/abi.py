@@ -39,6 +39,9 @@ SIGNATURES = {
     "itcv_conv2d_bf16s_supported": (i32, [i32, i32, i32]),
     "itcv_conv2d_packed_weight_bytes_bf16s": (sz, [i32] * 5),
     "itcv_conv2d_pack_weight_bf16s": (i32, [p, p, i32, i32, i32, i32, i32, p]),
+    "itcv_pack_desc_bytes": (sz, []),
+    "itcv_conv2d_pack_desc_bf16s": (i32, [p, p, p, i32, i32, i32, i32, i32, i32]),
+    "itcv_conv2d_pack_weights_bf16s": (i32, [p, i32, i32, i32, p]),
     "itcv_conv2d_fwd_bf16s_workspace": (sz, [i32] * 6),
     "itcv_conv2d_fwd_bf16s": (i32, [p, p, p, p] + [i32] * 8 + [p, sz, p]),
     "itcv_planes_bytes": (sz, [i32] * 4),

@@ -11,7 +11,7 @@ import weakref
 import torch
 
 from .abi import call, lib, ptr, stream
-from .functional import bump_weight_epoch
+from .functional import bump_weight_epoch, register_pack_group
 
 F32 = torch.float32
 
@@ -42,6 +42,7 @@ class FlatGroup:
                 p.data = self.flat_p[o:o + n].view(p.shape)
         self._ws = torch.empty(lib.itcv_sumsq_workspace(total), dtype=torch.uint8, device=dev)
         self._opt, self._parent = None, inherit
+        register_pack_group(self.params)       # their packed conv operands are refreshed by one launch per direction
         self.attach_grads()
         if inherit is not None:
             self._inherit(inherit)

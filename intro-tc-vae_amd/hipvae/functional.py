@@ -154,10 +154,11 @@ def conv_math_scope(mode):
         _CONV_MATH[0] = prev
 
 
-def packed_weight(weight, w4, for_dgrad, ns=0):
-    """Packed operand of ``weight`` (viewed as ``w4`` [Co,Ci,KS,KS]), cached until the weight changes:
-    the frozen half of the model is packed once per phase instead of once per network pass."""
-    key = (weight.data_ptr(), weight._version, _WEIGHT_EPOCH[0], _PARAM_EPOCH.get(id(weight), 0))
+def _pack_key(weight):
+    return (weight.data_ptr(), weight._version, _WEIGHT_EPOCH[0], _PARAM_EPOCH.get(id(weight), 0))
+
+
+def _pack_entry(weight, key):
     ent = _PACK_CACHE.get(id(weight))
     if ent is None:
         ent = _PACK_CACHE[id(weight)] = [key, {}]
@@ -165,10 +166,88 @@ def packed_weight(weight, w4, for_dgrad, ns=0):
         weakref.finalize(weight, _PARAM_EPOCH.pop, id(weight), None)
     elif ent[0] != key:
         ent[0], ent[1] = key, {}
+    return ent
+
+
+def packed_weight(weight, w4, for_dgrad, ns=0):
+    """Packed operand of ``weight`` (viewed as ``w4`` [Co,Ci,KS,KS]), cached until the weight changes:
+    the frozen half of the model is packed once per phase instead of once per network pass.  Weights registered
+    through register_pack_group() (the parameters of one optimiser) are re-packed together, one launch per
+    (direction, arithmetic), when the first of them is asked for after the optimiser step."""
+    ent = _pack_entry(weight, _pack_key(weight))
     wp = ent[1].get((for_dgrad, ns))
     if wp is None:
-        wp = ent[1][(for_dgrad, ns)] = pack_weight(w4, for_dgrad) if ns == 0 else pack_weight_bf16s(w4, for_dgrad, ns)
+        grp = _PACK_GROUPS.get(id(weight)) if ns and _PACK_BATCH[0] else None
+        if grp is not None:
+            wp = grp.pack(weight, w4, for_dgrad, ns)
+        else:
+            wp = ent[1][(for_dgrad, ns)] = pack_weight(w4, for_dgrad) if ns == 0 else pack_weight_bf16s(w4, for_dgrad, ns)
     return wp
+
+
+# One launch re-packs every split-bf16 conv weight of a parameter group (ITCV_PACK_BATCH=0: one launch per layer).
+_PACK_BATCH = [_os.environ.get("ITCV_PACK_BATCH", "1") != "0"]
+_PACK_GROUPS = {}
+
+
+class _PackGroup:
+    """Conv weights that change together.  Membership per (for_dgrad, ns) is learnt from the requests: a weight seen for
+    the first time is packed on its own and joins; from then on a miss on any member re-packs all of them into their
+    persistent buffers through one device-resident descriptor table."""
+
+    def __init__(self):
+        self.members = {}    # (for_dgrad, ns) -> {id(weight): [weakref(weight), (co, ci, ks), data_ptr, wp]}
+        self.tables = {}     # (for_dgrad, ns) -> (dev_table, n, total_blocks)
+
+    def pack(self, weight, w4, for_dgrad, ns):
+        k = (for_dgrad, ns)
+        mem = self.members.setdefault(k, {})
+        rec = mem.get(id(weight))
+        if rec is None or rec[2] != w4.data_ptr() or rec[1] != tuple(w4.shape[:3]):
+            wp = pack_weight_bf16s(w4, for_dgrad, ns)
+            mem[id(weight)] = [weakref.ref(weight), tuple(w4.shape[:3]), w4.data_ptr(), wp]
+            self.tables.pop(k, None)
+            _pack_entry(weight, _pack_key(weight))[1][k] = wp
+            return wp
+        tab = self.tables.get(k)
+        if tab is None:
+            for i in [i for i, r in mem.items() if r[0]() is None]:
+                del mem[i]
+            tab = self.tables[k] = self._build(mem, for_dgrad, ns, weight.device)
+        call("itcv_conv2d_pack_weights_bf16s", ptr(tab[0]), tab[1], tab[2], ns, stream())
+        for r in mem.values():
+            m = r[0]()
+            if m is not None:
+                _pack_entry(m, _pack_key(m))[1][k] = r[3]
+        return rec[3]
+
+    @staticmethod
+    def _build(mem, for_dgrad, ns, device):
+        import ctypes
+
+        nb = lib.itcv_pack_desc_bytes()
+        host = (ctypes.c_uint8 * (nb * len(mem)))()
+        blocks = 0
+        for i, r in enumerate(mem.values()):
+            co, ci, ks = r[1]
+            got = lib.itcv_conv2d_pack_desc_bf16s(ctypes.byref(host, i * nb), r[2], ptr(r[3]), co, ci, ks, int(for_dgrad), ns,
+                                                  blocks)
+            if got <= 0:
+                raise abi.HipExtensionError("itcv_conv2d_pack_desc_bf16s: " + abi.last_error())
+            blocks += got
+        dev_table = torch.frombuffer(bytearray(host), dtype=torch.uint8).to(device)
+        return dev_table, len(mem), blocks
+
+
+def register_pack_group(params):
+    """Parameters that one optimiser step changes together (hipvae.flat.FlatGroup): their packed conv operands are
+    refreshed by one launch per direction."""
+    grp = _PackGroup()
+    for p in params:
+        if p.dim() == 4:
+            _PACK_GROUPS[id(p)] = grp
+            weakref.finalize(p, _PACK_GROUPS.pop, id(p), None)
+    return grp
 
 
 def pack_weight_bf16s(w4, for_dgrad, ns):

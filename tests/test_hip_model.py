@@ -512,6 +512,45 @@ def test_batched_passes_equal_unbatched_step():
         assert rel_err(out[True][2][k], v) < 1e-5, k
 
 
+def test_group_weight_packing_equals_per_layer_packing():
+    """After an optimiser step the split-bf16 conv operands of a whole network are re-packed by one launch per
+    direction (device-resident descriptor table): three intro-TC steps at the benchmark shape are bit-identical to
+    packing layer by layer, and the batched path was really taken."""
+    import models
+    import ops
+    from hipvae import functional as HF
+    torch.manual_seed(3)
+    init = models.SoftIntroVAE(arch="res", **C2).state_dict()
+    hp = [0.5, 0.75, 512.0, 1e-8, 100.0, 2e-4, 10000]
+    g = torch.Generator().manual_seed(5)
+    xs = [torch.rand(8, 3, 64, 64, generator=g).to(dev()) for _ in range(3)]
+    draws = [[torch.randn(8, 128, generator=g).to(dev()) for _ in range(6)] for _ in range(3)]
+    out, tables = {}, 0
+    for batched in (True, False):
+        HF._PACK_BATCH[0] = batched
+        try:
+            model = models.SoftIntroVAE(arch="res", **C2)
+            model.load_state_dict(init)
+            model = model.to(dev()).train()
+            solver = make_solver("intro_tc", model, hp, math="bf16x3")
+            solver.batch_size = 8
+            res = []
+            for s in range(3):
+                with ops.noise_queue([t.clone() for t in draws[s]]):
+                    res.append(solver.train_step(xs[s], s))
+            if batched:
+                grp = {id(v): v for v in (HF._PACK_GROUPS.get(id(p)) for p in model.parameters()) if v is not None}
+                assert len(grp) == 2                                    # encoder and decoder
+                tables = sum(len(v.tables) for v in grp.values())
+                assert all(t[1] > 4 for v in grp.values() for t in v.tables.values())
+        finally:
+            HF._PACK_BATCH[0] = True
+        out[batched] = (res, torch.cat([p.detach().reshape(-1) for p in model.parameters()]).cpu())
+    assert tables >= 3                                                  # forward + data-gradient tables were built
+    assert out[True][0] == out[False][0]
+    assert torch.equal(out[True][1], out[False][1])
+
+
 def test_adam_state_roundtrip_and_ownership_carryover():
     """The fused Adam's moments live in flat buffers; they are mirrored into ``optimizer.state`` (so
     ``optimizer.state_dict()`` / ``load_state_dict()`` round-trip) and carried over when the parameters are moved
