@@ -342,22 +342,39 @@ __global__ __launch_bounds__(256) void bn_act_fwd_planes_kernel(
       __syncthreads();
       const uint32_t last = min(base + blockDim.x, total) - 1, ng = last / per_plane - g0 + 1;
       if (threadIdx.x < ng * 8) {
+        // BatchNorm groups (blockIdx.z): every group folds its own partial sums; the running buffers advance group by
+        // group, so the recording thread of group 0 folds the later groups as well and applies them in order
+        const uint32_t gz = blockIdx.z, G = grp.G > 1 ? grp.G : 1;
         const uint32_t g = g0 + threadIdx.x / 8, c = (g % C8) * 8 + (threadIdx.x & 7);
-        const double s1 = fold_strided(0.0, st.part + c, (size_t)2 * C, st.splits);
-        const double s2 = fold_strided(0.0, st.part + C + c, (size_t)2 * C, st.splits);
+        const double* part = st.part + (size_t)gz * st.splits * 2 * C;
+        const double s1 = fold_strided(0.0, part + c, (size_t)2 * C, st.splits);
+        const double s2 = fold_strided(0.0, part + C + c, (size_t)2 * C, st.splits);
         const double m = s1 / st.count;
         double var = s2 / st.count - m * m;
         if (var < 0.0) var = 0.0;
         const float mf = (float)m, rf = (float)(1.0 / sqrt(var + (double)st.eps));
         s_mean[threadIdx.x] = mf, s_rstd[threadIdx.x] = rf;
         if (g < (uint32_t)C8 && g * per_plane >= base) {   // image 0, and the group starts inside this block
-          st.mean_out[c] = mf, st.rstd_out[c] = rf;
-          if (st.running_mean) st.running_mean[c] = (1.f - st.momentum) * st.running_mean[c] + st.momentum * mf;
-          if (st.running_var) {
-            const double unbiased = st.count > 1.0 ? var * st.count / (st.count - 1.0) : var;
-            st.running_var[c] = (1.f - st.momentum) * st.running_var[c] + st.momentum * (float)unbiased;
+          st.mean_out[(size_t)gz * C + c] = mf, st.rstd_out[(size_t)gz * C + c] = rf;
+          if (gz == 0) {
+            double mg = m, vg = var;
+            for (uint32_t gg = 0; gg < G; ++gg) {
+              if (gg) {
+                const double* pg = st.part + (size_t)gg * st.splits * 2 * C;
+                const double t1 = fold_strided(0.0, pg + c, (size_t)2 * C, st.splits);
+                const double t2 = fold_strided(0.0, pg + C + c, (size_t)2 * C, st.splits);
+                mg = t1 / st.count;
+                vg = t2 / st.count - mg * mg;
+                if (vg < 0.0) vg = 0.0;
+              }
+              if (st.running_mean) st.running_mean[c] = (1.f - st.momentum) * st.running_mean[c] + st.momentum * (float)mg;
+              if (st.running_var) {
+                const double unbiased = st.count > 1.0 ? vg * st.count / (st.count - 1.0) : vg;
+                st.running_var[c] = (1.f - st.momentum) * st.running_var[c] + st.momentum * (float)unbiased;
+              }
+            }
+            if (c == 0 && st.nbt) st.nbt[0] += G;
           }
-          if (c == 0 && st.nbt) st.nbt[0] += 1;
         }
       }
       __syncthreads();
@@ -660,14 +677,27 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_planes(
       __syncthreads();
       const uint32_t last = min(base + blockDim.x, total) - 1, ng = last / per_plane - g0 + 1;
       if (threadIdx.x < ng * 8) {
+        // BatchNorm groups (blockIdx.z): own partial sums per group; the parameter gradients add up over the groups in
+        // order, done by the recording thread of group 0
+        const uint32_t gz = blockIdx.z, G = grp.G > 1 ? grp.G : 1;
         const uint32_t g = g0 + threadIdx.x / 8, c = (g % C8) * 8 + (threadIdx.x & 7);
-        const double s1 = fold_strided(0.0, sm.part + c, (size_t)2 * C, sm.splits);
-        const double s2 = fold_strided(0.0, sm.part + C + c, (size_t)2 * C, sm.splits);
+        const double* part = sm.part + (size_t)gz * sm.splits * 2 * C;
+        const double s1 = fold_strided(0.0, part + c, (size_t)2 * C, sm.splits);
+        const double s2 = fold_strided(0.0, part + C + c, (size_t)2 * C, sm.splits);
         s_m1[threadIdx.x] = (float)(s1 / count), s_m2[threadIdx.x] = (float)(s2 / count);
         if (g < C8 && g * per_plane >= base) {
-          sm.dsums_out[c] = s1, sm.dsums_out[C + c] = s2;
-          if (sm.dbeta) sm.dbeta[c] = (sm.accumulate ? sm.dbeta[c] : 0.f) + (float)s1;
-          if (sm.dgamma) sm.dgamma[c] = (sm.accumulate ? sm.dgamma[c] : 0.f) + (float)s2;
+          sm.dsums_out[(size_t)gz * 2 * C + c] = s1, sm.dsums_out[(size_t)gz * 2 * C + C + c] = s2;
+          if (gz == 0) {
+            float db = (sm.accumulate && sm.dbeta) ? sm.dbeta[c] : 0.f, dg = (sm.accumulate && sm.dgamma) ? sm.dgamma[c] : 0.f;
+            db += (float)s1, dg += (float)s2;
+            for (uint32_t gg = 1; gg < G; ++gg) {
+              const double* pg = sm.part + (size_t)gg * sm.splits * 2 * C;
+              db += (float)fold_strided(0.0, pg + c, (size_t)2 * C, sm.splits);
+              dg += (float)fold_strided(0.0, pg + C + c, (size_t)2 * C, sm.splits);
+            }
+            if (sm.dbeta) sm.dbeta[c] = db;
+            if (sm.dgamma) sm.dgamma[c] = dg;
+          }
         }
       }
       __syncthreads();
@@ -1112,21 +1142,32 @@ int itcv_bn_train_fwd(const float* x, const float* gamma, const float* beta, con
       hipLaunchKernelGGL(bn_moments_partial<false>, dim3(C, gsplits, groups), dim3(kRedThreads), 0, S(stream), x, part, B, C,
                          HWg, gsplits, ilog2_exact(HWg), BnFinal{}, grp);
       ITCV_CHECK_LAUNCH("itcv_bn_train_fwd(grouped partials)");
-      hipLaunchKernelGGL(bn_combine_finalize_groups_kernel, dim3(cdiv(C, 256)), dim3(256), 0, S(stream), part, gsplits, groups,
-                         (double)B * HWg, eps, momentum, running_mean, running_var, num_batches_tracked, mean, rstd, C);
-      ITCV_CHECK_LAUNCH("itcv_bn_train_fwd(grouped finalize)");
+      const int per_plane_g = pool ? (HWg / 4) / 2 : HWg / 4;
+      const bool fold_in_apply = per_plane_g >= 64 && bn_fuse_finalize();   // the apply pass folds the partial sums itself
+      if (!fold_in_apply) {
+        hipLaunchKernelGGL(bn_combine_finalize_groups_kernel, dim3(cdiv(C, 256)), dim3(256), 0, S(stream), part, gsplits,
+                           groups, (double)B * HWg, eps, momentum, running_mean, running_var, num_batches_tracked, mean, rstd,
+                           C);
+        ITCV_CHECK_LAUNCH("itcv_bn_train_fwd(grouped finalize)");
+      }
+      const BnStatsIn stg{part, gsplits, (double)B * HWg, eps, momentum, running_mean, running_var, num_batches_tracked, mean,
+                          rstd};
       const size_t threads = (size_t)B * (C / 8) * (HWo / (pool ? 2 : 4));
       const dim3 grid(grid_for(threads), 1, groups), blk(256);
       u32x4* pl = static_cast<u32x4*>(planes);
       const bool strip = bn_strip_mask() & 1;
+#define ITCV_FWD_GRP2_K(POOL_, NS_, ST_, STRIP_)                                                                          \
+  hipLaunchKernelGGL((bn_act_fwd_planes_kernel<POOL_, NS_, ST_, STRIP_>), grid, blk, 0, S(stream), x, mean, rstd, gamma, beta, \
+                     skip, y, pl, B, C, H, W, slope, (ST_) ? stg : BnStatsIn{}, plane_stride, grp)
 #define ITCV_FWD_GRP2(POOL_, NS_)                                                                                         \
   do {                                                                                                                    \
-    if (strip)                                                                                                            \
-      hipLaunchKernelGGL((bn_act_fwd_planes_kernel<POOL_, NS_, false, true>), grid, blk, 0, S(stream), x, mean, rstd, gamma,   \
-                         beta, skip, y, pl, B, C, H, W, slope, BnStatsIn{}, plane_stride, grp);                             \
-    else                                                                                                                  \
-      hipLaunchKernelGGL((bn_act_fwd_planes_kernel<POOL_, NS_, false, false>), grid, blk, 0, S(stream), x, mean, rstd, gamma,  \
-                         beta, skip, y, pl, B, C, H, W, slope, BnStatsIn{}, plane_stride, grp);                             \
+    if (fold_in_apply) {                                                                                                  \
+      if (strip) ITCV_FWD_GRP2_K(POOL_, NS_, true, true);                                                                 \
+      else ITCV_FWD_GRP2_K(POOL_, NS_, true, false);                                                                      \
+    } else {                                                                                                              \
+      if (strip) ITCV_FWD_GRP2_K(POOL_, NS_, false, true);                                                                \
+      else ITCV_FWD_GRP2_K(POOL_, NS_, false, false);                                                                     \
+    }                                                                                                                     \
   } while (0)
       if (pool) {
         if (ns == 2) ITCV_FWD_GRP2(1, 2);
@@ -1135,6 +1176,7 @@ int itcv_bn_train_fwd(const float* x, const float* gamma, const float* beta, con
         if (ns == 2) ITCV_FWD_GRP2(0, 2);
         else ITCV_FWD_GRP2(0, 3);
       }
+#undef ITCV_FWD_GRP2_K
 #undef ITCV_FWD_GRP2
       ITCV_CHECK_LAUNCH("itcv_bn_train_fwd(grouped apply)");
       return 0;
@@ -1251,18 +1293,26 @@ int itcv_bn_train_bwd(const float* x, const float* dy, const float* mean, const 
       const dim3 rgrid(C, gsplits, groups), agrid(grid_for(xs / 32), 1, groups), blk(256);
       u32x4* pl = static_cast<u32x4*>(dx_planes);
       const double count = (double)B * HWg;
+      const bool fold_in_apply = HWg / 4 >= 64 && bn_fuse_finalize();   // the apply pass folds the partial sums itself
+      const BnBwdSumsIn smg{part, gsplits, dsums, dgamma, dbeta, accumulate};
+#define ITCV_BWD_GRP2_K(MODE_, NS_, SUMS_, STRIP_)                                                                       \
+  hipLaunchKernelGGL((bn_bwd_apply_planes<MODE_, NS_, SUMS_, STRIP_>), agrid, blk, 0, st, x, dy, mean, rstd, gamma, beta,  \
+                     skip, (SUMS_) ? static_cast<const double*>(nullptr) : dsums, count, dx, dskip, pl, B, C, H, W, slope, \
+                     wsh, (SUMS_) ? smg : BnBwdSumsIn{}, plane_stride, grp)
 #define ITCV_BWD_GRP2(MODE_, NS_)                                                                                        \
   do {                                                                                                                   \
     hipLaunchKernelGGL((bn_bwd_partial_v4<MODE_, false>), rgrid, dim3(kRedThreads), 0, st, x, dy, mean, rstd, gamma, beta,  \
                        skip, part, B, C, H, W, slope, gsplits, wsh, hwsh, BnBwdFinal{}, grp);                            \
-    hipLaunchKernelGGL(bn_combine_param_groups_kernel, dim3(cdiv(C, 256)), dim3(256), 0, st, part, dsums, C, gsplits,     \
-                       groups, dgamma, dbeta, accumulate);                                                               \
-    if (bn_strip_mask() & ((MODE_) == 0 ? 2 : 4))                                                                        \
-      hipLaunchKernelGGL((bn_bwd_apply_planes<MODE_, NS_, false, true>), agrid, blk, 0, st, x, dy, mean, rstd, gamma, beta,  \
-                         skip, dsums, count, dx, dskip, pl, B, C, H, W, slope, wsh, BnBwdSumsIn{}, plane_stride, grp);     \
-    else                                                                                                                 \
-      hipLaunchKernelGGL((bn_bwd_apply_planes<MODE_, NS_, false, false>), agrid, blk, 0, st, x, dy, mean, rstd, gamma, beta, \
-                         skip, dsums, count, dx, dskip, pl, B, C, H, W, slope, wsh, BnBwdSumsIn{}, plane_stride, grp);     \
+    const bool strip_ = bn_strip_mask() & ((MODE_) == 0 ? 2 : 4);                                                        \
+    if (fold_in_apply) {                                                                                                 \
+      if (strip_) ITCV_BWD_GRP2_K(MODE_, NS_, true, true);                                                               \
+      else ITCV_BWD_GRP2_K(MODE_, NS_, true, false);                                                                     \
+    } else {                                                                                                             \
+      hipLaunchKernelGGL(bn_combine_param_groups_kernel, dim3(cdiv(C, 256)), dim3(256), 0, st, part, dsums, C, gsplits,   \
+                         groups, dgamma, dbeta, accumulate);                                                             \
+      if (strip_) ITCV_BWD_GRP2_K(MODE_, NS_, false, true);                                                              \
+      else ITCV_BWD_GRP2_K(MODE_, NS_, false, false);                                                                    \
+    }                                                                                                                    \
   } while (0)
 #define ITCV_BWD_GRP2_NS(MODE_)            \
   do {                                     \
@@ -1274,6 +1324,7 @@ int itcv_bn_train_bwd(const float* x, const float* dy, const float* mean, const 
       else ITCV_BWD_GRP2_NS(0);
 #undef ITCV_BWD_GRP2_NS
 #undef ITCV_BWD_GRP2
+#undef ITCV_BWD_GRP2_K
       ITCV_CHECK_LAUNCH("itcv_bn_train_bwd(grouped, sliced)");
       return 0;
     }
