@@ -1405,13 +1405,16 @@ __device__ __forceinline__ void tr_read8(bf16x8& dst, uint32_t addr0, uint32_t a
   dst = __builtin_bit_cast(bf16x8, v);
 }
 
-template <int LOG2W, bool UP2, int BM, int BN, int NST, int NLW>
+// KH = 2 (the 64 x 64 tile): the eight MFMA waves are two groups of four that take alternate halves of a step's four
+// 16-pixel k-steps and keep separate slabs (slab index split*KH + kh) -- the tile is too small for eight waves otherwise.
+template <int LOG2W, bool UP2, int BM, int BN, int NST, int NLW, int KH = 1>
 __global__ __launch_bounds__(512 + 64 * NLW) void conv_wgrad_bf16p_kernel(WgradArgsP a) {
   constexpr int W = 1 << LOG2W, NR = 64 >> LOG2W, WP = W + 2, NP = NR * WP;   // band: NR rows x (W+2) columns
   constexpr int PXA = 68, PXB = ((NP + 11) / 16) * 16 + 4;                     // row strides = 4 (mod 16) chunks: conflict-free tr reads
   static_assert(PXB >= NP && PXB % 16 == 4, "band stride");
   constexpr int ACH = BM / 8, BCH = BN / 8;                                    // 128 x 128, 128 x 64 or 64 x 128 (co x ci)
-  constexpr int WMn = BM / 32, WNn = 8 / WMn, TNw = BN / (32 * WNn);          // 32 x 32*TNw accumulators x 3 taps per wave
+  constexpr int WMn = BM / 32, WNn = (8 / KH) / WMn, TNw = BN / (32 * WNn), KPW = 4 / KH;   // KPW: k-steps per wave
+  static_assert(KH == 1 || KH == 2, "k-halves");          // 32 x 32*TNw accumulators x 3 taps per wave
   static_assert(TNw >= 1 && BN == 32 * WNn * TNw, "wave tiling");
   constexpr int ASZ = 2 * ACH * PXA, BSZ = 2 * BCH * PXB, SSZ = ASZ + BSZ;     // chunks per stage
   extern __shared__ u32x4 smem[];
@@ -1508,7 +1511,8 @@ __global__ __launch_bounds__(512 + 64 * NLW) void conv_wgrad_bf16p_kernel(WgradA
   }
 
   // -------------------------------------------------------------------- MFMA waves
-  const int wm = wid / WNn, wn = wid % WNn;
+  const int kh = wid / (8 / KH), w8 = wid % (8 / KH);
+  const int wm = w8 / WNn, wn = w8 % WNn;
   const int G = lane >> 4, i16 = lane & 15, q = i16 >> 2, pp = i16 & 3, half = G >> 1, rb = G & 1;
   const int l31 = lane & 31;
   f32x16 acc[3][TNw];
@@ -1523,10 +1527,10 @@ __global__ __launch_bounds__(512 + 64 * NLW) void conv_wgrad_bf16p_kernel(WgradA
     const uint32_t aoff = (uint32_t)(((4 * wm + 2 * rb + (pp >> 1)) * PXA + half * 8 + q) * 16 + (pp & 1) * 8);
     const uint32_t boff = (uint32_t)((ASZ + (4 * wn * TNw + 2 * rb + (pp >> 1)) * PXB) * 16 + (pp & 1) * 8);
     // band index of pixel k = kk*16 + half*8 + s*4 + q, for the 8 (kk, s) pairs, centre tap
-    uint32_t hidx16[8];
+    uint32_t hidx16[2 * KPW];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const int k = (u >> 1) * 16 + half * 8 + (u & 1) * 4 + q;
+    for (int u = 0; u < 2 * KPW; ++u) {
+      const int k = ((u >> 1) + kh * KPW) * 16 + half * 8 + (u & 1) * 4 + q;
       hidx16[u] = (uint32_t)(((k >> LOG2W) * WP + (k & (W - 1)) + 1) * 16);
     }
     __builtin_amdgcn_s_barrier();
@@ -1542,7 +1546,7 @@ __global__ __launch_bounds__(512 + 64 * NLW) void conv_wgrad_bf16p_kernel(WgradA
         auto fetch = [&](int kk, int bufi) {
 #pragma unroll
           for (int pl = 0; pl < 2; ++pl) {
-            const uint32_t ad = sb + aoff + (uint32_t)(pl * ACH * PXA * 16 + kk * 256);
+            const uint32_t ad = sb + aoff + (uint32_t)(pl * ACH * PXA * 16 + (kh * KPW + kk) * 256);
             tr_read8(af[bufi][pl], ad, ad + 64);
           }
 #pragma unroll
@@ -1555,9 +1559,9 @@ __global__ __launch_bounds__(512 + 64 * NLW) void conv_wgrad_bf16p_kernel(WgradA
         };
         fetch(0, 0);
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
+        for (int kk = 0; kk < KPW; ++kk) {
           const int cur = kk & 1;
-          if (kk + 1 < 4) fetch(kk + 1, cur ^ 1);
+          if (kk + 1 < KPW) fetch(kk + 1, cur ^ 1);
 #pragma unroll
           for (int tp = 0; tp < 3; ++tp) {
             f32x16 c = acc[tp][0];
@@ -1567,7 +1571,7 @@ __global__ __launch_bounds__(512 + 64 * NLW) void conv_wgrad_bf16p_kernel(WgradA
             acc[tp][0] = c;
           }
           if (kk == 0) __builtin_amdgcn_sched_group_barrier(0x100, 16, 0);   // the first k-step's own reads
-          if (kk + 1 < 4) {
+          if (kk + 1 < KPW) {
 #pragma unroll
             for (int r = 0; r < 8; ++r) {
               __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -1579,6 +1583,7 @@ __global__ __launch_bounds__(512 + 64 * NLW) void conv_wgrad_bf16p_kernel(WgradA
           }
         }
       } else {
+      static_assert(TNw == 1 || KH == 1, "k-halves only with one accumulator column per wave");
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk) {
         bf16x8 af[2];
@@ -1621,7 +1626,7 @@ __global__ __launch_bounds__(512 + 64 * NLW) void conv_wgrad_bf16p_kernel(WgradA
     if (ci >= a.Ci) continue;
 #pragma unroll
     for (int tp = 0; tp < 3; ++tp) {
-      float* out = a.slab + ((size_t)(split * 9 + dhi * 3 + tp) * a.Co) * a.Ci + ci;
+      float* out = a.slab + ((size_t)((split * KH + kh) * 9 + dhi * 3 + tp) * a.Co) * a.Ci + ci;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int co = co0 + 32 * wm + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
@@ -2084,7 +2089,16 @@ static void launch_fwd_p(const ConvArgsP& a, int bm, int splits, int up2, hipStr
 
 struct WgPlanP {
   int bm, bn, tiles_m, tiles_n, steps, splits, sps;
+  int kh;   // slabs per K slice (2 for the 64 x 64 tile: its wave groups keep separate slabs)
 };
+static int wgrad_p_small() {   // ITCV_WGP_SMALL=0: no 64 x 64 tile (diagnostic)
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("ITCV_WGP_SMALL");
+    v = (e && e[0] == '0') ? 0 : 1;
+  }
+  return v;
+}
 static int wgrad_p_wide() {   // ITCV_WGP_WIDE=0: 128 x 64 tiles only (diagnostic)
   static int v = -1;
   if (v < 0) {
@@ -2097,6 +2111,9 @@ static WgPlanP plan_wgrad_p(int B, int Ci, int H, int W, int Co) {
   WgPlanP p;
   p.bm = (Co <= 64 && Ci >= 128) ? 64 : 128;    // 64 x 128 (co x ci) tiles when the output side is narrow
   p.bn = 8192 / p.bm;
+  p.kh = 1;
+  // 64 -> 64 channels: a 128-row tile would multiply 64 rows of zeros; 64 x 64 with the waves split over the k-steps
+  if (Co <= 64 && Ci <= 64 && wgrad_p_small()) p.bm = 64, p.bn = 64, p.kh = 2;
   // 128 x 128 tiles halve the operand bytes per MFMA (the 128 x 64 form runs near the ~30 B/clk/CU ingest limit) but
   // double the slab a block writes: measured faster only for the widest layers, where few K slices are needed
   if (p.bm == 128 && Ci >= 512 && Co >= 256 && W >= 8 && wgrad_p_wide()) p.bn = 128;
@@ -2118,7 +2135,7 @@ static WgPlanP plan_wgrad_p(int B, int Ci, int H, int W, int Co) {
   return p;
 }
 
-template <int LOG2W, bool UP2, int BM, int BN>
+template <int LOG2W, bool UP2, int BM, int BN, int KH = 1>
 static void launch_wgrad_p_cfg(const WgradArgsP& a, int blocks, hipStream_t st) {
   constexpr int W = 1 << LOG2W, NP = (64 >> LOG2W) * (W + 2), PXB = ((NP + 11) / 16) * 16 + 4;
   constexpr size_t stage_bytes = (size_t)(2 * (BM / 8) * 68 + 2 * (BN / 8) * PXB) * 16;
@@ -2126,7 +2143,7 @@ static void launch_wgrad_p_cfg(const WgradArgsP& a, int blocks, hipStream_t st) 
   constexpr size_t lds = NST * stage_bytes;
   if constexpr (lds <= 160 * 1024) {
     constexpr int NLW = 4;   // loader waves (eight were measured no faster, and spill in the 128 x 128 form)
-    auto kern = conv_wgrad_bf16p_kernel<LOG2W, UP2, BM, BN, NST, NLW>;
+    auto kern = conv_wgrad_bf16p_kernel<LOG2W, UP2, BM, BN, NST, NLW, KH>;
     static bool attr_set = false;
     if (!attr_set) {
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -2137,7 +2154,10 @@ static void launch_wgrad_p_cfg(const WgradArgsP& a, int blocks, hipStream_t st) 
 }
 template <int LOG2W>
 static void launch_wgrad_p(const WgradArgsP& a, int bm, int bn, int up2, int blocks, hipStream_t st) {
-  if (bm == 64) {
+  if (bm == 64 && bn == 64) {
+    if (up2) launch_wgrad_p_cfg<LOG2W, true, 64, 64, 2>(a, blocks, st);
+    else launch_wgrad_p_cfg<LOG2W, false, 64, 64, 2>(a, blocks, st);
+  } else if (bm == 64) {
     if (up2) launch_wgrad_p_cfg<LOG2W, true, 64, 128>(a, blocks, st);
     else launch_wgrad_p_cfg<LOG2W, false, 64, 128>(a, blocks, st);
   } else if (bn == 128) {
@@ -2632,7 +2652,7 @@ int itcv_conv2d_wgrad_bf16p_supported(int B, int Ci, int H, int W, int Co, int K
 size_t itcv_conv2d_wgrad_bf16p_workspace(int B, int Ci, int H, int W, int Co, int KS) {
   if (!itcv_conv2d_wgrad_bf16p_supported(B, Ci, H, W, Co, KS)) return 0;
   const WgPlanP p = plan_wgrad_p(B, Ci, H, W, Co);
-  return (size_t)p.splits * 9 * Co * Ci * sizeof(float);
+  return (size_t)p.splits * p.kh * 9 * Co * Ci * sizeof(float);
 }
 
 // dw[Co][Ci][3][3] (+)= conv weight gradient from the pre-split planes of x ([2][B][Ci/8][Hs][Ws]; Hs,Ws =
@@ -2645,7 +2665,7 @@ int itcv_conv2d_wgrad_bf16p(const void* xplanes, const void* dyplanes, float* dw
     return fail("%s: shape not supported (KS 3, W a power of two in 4..256, H a power of two, C %% 8)", "itcv_conv2d_wgrad_bf16p");
   if (up2) ITCV_REQUIRE(H % 2 == 0 && W % 2 == 0, "itcv_conv2d_wgrad_bf16p(up2)");
   const WgPlanP p = plan_wgrad_p(B, Ci, H, W, Co);
-  const size_t need = (size_t)p.splits * 9 * Co * Ci * sizeof(float);
+  const size_t need = (size_t)p.splits * p.kh * 9 * Co * Ci * sizeof(float);
   if (!ws || ws_bytes < need) return fail("%s: workspace too small (need %lld bytes)", "itcv_conv2d_wgrad_bf16p", (long long)need);
   WgradArgsP a;
   a.xp = static_cast<const u32x4*>(xplanes), a.dyp = static_cast<const u32x4*>(dyplanes);
@@ -2677,7 +2697,7 @@ int itcv_conv2d_wgrad_bf16p(const void* xplanes, const void* dyplanes, float* dw
   const int coci = Co * Ci;
   const size_t rthreads = (size_t)coci * 9;
   hipLaunchKernelGGL(wgrad_p_reduce, dim3((int)(cdivz(rthreads, 256) < 8192 ? cdivz(rthreads, 256) : 8192)), dim3(256), 0,
-                     st, static_cast<const float*>(ws), dw, coci, p.splits, accumulate);
+                     st, static_cast<const float*>(ws), dw, coci, p.splits * p.kh, accumulate);
   ITCV_CHECK_LAUNCH("itcv_conv2d_wgrad_bf16p(reduce)");
   return 0;
 }

@@ -84,6 +84,8 @@ WGRAD_CASES = [  # B, Ci, H, W, Co, up2
     (2, 128, 16, 16, 64, True), (2, 512, 8, 8, 256, False), (8, 24, 8, 8, 136, False),
     # images wider than the 64-pixel band: one 64-column segment of a row per step (128x128 / 256x256 configurations)
     (1, 64, 8, 128, 64, False), (2, 32, 4, 256, 128, False), (1, 64, 16, 128, 32, True), (1, 16, 8, 256, 64, True),
+    # 64 x 64 tile (both sides <= 64 channels): wave groups over the k-steps of a step, separate slabs
+    (3, 64, 64, 64, 64, True), (8, 40, 8, 8, 56, False), (4, 64, 4, 4, 64, False),
 ]
 
 
