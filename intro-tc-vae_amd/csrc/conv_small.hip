@@ -140,7 +140,7 @@ __global__ __launch_bounds__(256) void conv_small_cout_planes_kernel(const u32x4
   constexpr int KS = 5, KK = 25, C = 64, C8 = 8;
   __shared__ float zs[4][16 * 17];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int job = blockIdx.x * 4 + wv;
+  const int job = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + wv);   // wave-uniform: addresses go to SGPRs
   if (job >= njobs) return;
   const int s = job % strips, rbk = (job / strips) % row_blocks, b = job / (strips * row_blocks);
   const int n = lane & 15, kg = lane >> 4;
@@ -184,15 +184,17 @@ __global__ __launch_bounds__(256) void conv_small_cout_planes_kernel(const u32x4
 #pragma unroll
   for (int i = 0; i < 5; ++i) acc[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
   const int nrows = min(RB, H - h0);       // output rows of this job
-  u32x4 cur[2][2], nxt[2][2];
+  // two input rows in flight behind the one being multiplied: a row's 30 MFMAs alone do not cover a global-memory round trip
+  u32x4 cur[2][2], nxt[2][2], nx2[2][2];
   load_row(h0 - 2, cur);
+  load_row(h0 - 1, nxt);
   float* zt = zs[wv];
   for (int i0 = 0; i0 < nrows + 4; i0 += 5) {
 #pragma unroll
     for (int r = 0; r < 5; ++r) {
       const int i = i0 + r;                // input row h0 - 2 + i
       if (i >= nrows + 4) break;
-      load_row(h0 - 2 + i + 1, nxt);
+      load_row(h0 - 2 + i + 2, nx2);
       // output row o = i - kh (kh = 0..4 = dh + 2) takes filter row kh; its accumulator slot is o mod 5
 #pragma unroll
       for (int kh = 0; kh < 5; ++kh) {
@@ -229,7 +231,7 @@ __global__ __launch_bounds__(256) void conv_small_cout_planes_kernel(const u32x4
 #pragma unroll
       for (int hf = 0; hf < 2; ++hf)
 #pragma unroll
-        for (int p = 0; p < 2; ++p) cur[hf][p] = nxt[hf][p];
+        for (int p = 0; p < 2; ++p) cur[hf][p] = nxt[hf][p], nxt[hf][p] = nx2[hf][p];
     }
   }
 }
@@ -239,12 +241,12 @@ __global__ __launch_bounds__(256) void conv_small_cout_planes_kernel(const u32x4
 // output channels, columns 32 pixels of an image row, and the reduction index of one 32x32x16 product is (dw, ci) --
 // 5*CI <= 15 of 16 slots -- for ONE filter row dh; the five filter rows accumulate into the same tile.  A lane's B
 // fragment of an input row is 8 fp32 pixels read straight from the image (column n + dw - 2 of channel ci), split into
-// two bf16 planes once and kept for the five output rows that touch it (a ring of five fragments while the wave walks
+// two bf16 planes once and kept for the five output rows that touch it (a ring of six fragments while the wave walks
 // down its strip), the weights (5 x 2 x 2 fragments) stay in registers: per output row a wave issues 8 loads,
 // 30 MFMAs and 32 128-byte store segments.
 typedef float f32x16_t __attribute__((ext_vector_type(16)));
 
-template <int CI, bool DGRAD>
+template <int CI, bool DGRAD, int AHEAD>
 __global__ __launch_bounds__(256, 2) void conv_small_cin_mfma_kernel(const float* __restrict__ x,
                                                                  const float* __restrict__ w,
                                                                  const float* __restrict__ bias, float* __restrict__ y,
@@ -305,18 +307,20 @@ __global__ __launch_bounds__(256, 2) void conv_small_cin_mfma_kernel(const float
     for (int j = 0; j < 8; ++j) v[j] = (rok && offj[j] >= 0) ? xr[offj[j]] : 0.f;
     split8<2>(v, dst);
   };
-  // ring of input-row fragments: slot q holds input row h0 - 2 + i with i % 5 == q
-  u32x4 ring[5][2];
+  // ring of R = 5 + AHEAD input-row fragments: slot q holds input row h0 - 2 + i with i % R == q; AHEAD = 1 requests the
+  // row that completes output row o + 1 while row o is multiplied
+  constexpr int R = 5 + AHEAD;
+  u32x4 ring[R][2];
 #pragma unroll
-  for (int q = 0; q < 4; ++q) load_row(h0 - 2 + q, ring[q]);
+  for (int q = 0; q < R - 1; ++q) load_row(h0 - 2 + q, ring[q]);
   float* yb = y + (size_t)b * M * HW;            // uniform
   const int lane_off = 4 * kg * (int)HW + w0 + n;
-  for (int o0 = 0; o0 < nrows; o0 += 5) {
+  for (int o0 = 0; o0 < nrows; o0 += R) {
 #pragma unroll
-    for (int u = 0; u < 5; ++u) {
+    for (int u = 0; u < R; ++u) {
       const int o = o0 + u;                      // output row h0 + o needs input rows i = o .. o + 4
       if (o >= nrows) break;
-      load_row(h0 + o + 2, ring[(u + 4) % 5]);
+      load_row(h0 - 2 + o + R - 1, ring[(u + R - 1) % R]);
       f32x16_t acc[2];
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt)
@@ -324,8 +328,8 @@ __global__ __launch_bounds__(256, 2) void conv_small_cin_mfma_kernel(const float
         for (int r = 0; r < 16; ++r) acc[mt][r] = 0.f;
 #pragma unroll
       for (int dh = 0; dh < 5; ++dh) {
-        const bf16x8 b0 = __builtin_bit_cast(bf16x8, ring[(u + dh) % 5][0]),
-                     b1 = __builtin_bit_cast(bf16x8, ring[(u + dh) % 5][1]);
+        const bf16x8 b0 = __builtin_bit_cast(bf16x8, ring[(u + dh) % R][0]),
+                     b1 = __builtin_bit_cast(bf16x8, ring[(u + dh) % R][1]);
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) {
           acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[dh][mt][0], b1, acc[mt], 0, 0, 0);
@@ -481,18 +485,30 @@ int itcv_conv2d_small_cin_fwd_bf16x3(const float* x, const float* w, const float
   const int njobs = B * row_blocks * strips;
   hipStream_t st = S(stream);
   ProfScope prof(st, 5, KS, C, 0, 2, 2.0 * B * H * W * (double)Co * C * KS * KS);
-#define ITCV_SCIN_M(CI_)                                                                                              \
-  do {                                                                                                                \
-    if (for_dgrad)                                                                                                    \
-      launch_timed((conv_small_cin_mfma_kernel<CI_, true>), dim3(cdiv(njobs, 4)), dim3(256), 0, st, x, w, bias, y, H, \
-                   W, strips, row_blocks, RB, njobs);                                                                 \
-    else                                                                                                              \
-      launch_timed((conv_small_cin_mfma_kernel<CI_, false>), dim3(cdiv(njobs, 4)), dim3(256), 0, st, x, w, bias, y, H, \
-                   W, strips, row_blocks, RB, njobs);                                                                 \
+  // ITCV_SCIN_AHEAD=1: request each input row one output row ahead of its use (diagnostic).  Measured slower
+  // (37 -> 43 us at 128 x 3 x 64 x 64): the kernel is bound by its 134 MB of stores, and the longer ring costs registers.
+  static int ahead = -1;
+  if (ahead < 0) {
+    const char* e = getenv("ITCV_SCIN_AHEAD");
+    ahead = (e && e[0] == '1') ? 1 : 0;
+  }
+#define ITCV_SCIN_K(CI_, DG_, AH_)                                                                                    \
+  launch_timed((conv_small_cin_mfma_kernel<CI_, DG_, AH_>), dim3(cdiv(njobs, 4)), dim3(256), 0, st, x, w, bias, y, H, W, \
+               strips, row_blocks, RB, njobs)
+#define ITCV_SCIN_M(CI_)                                        \
+  do {                                                          \
+    if (for_dgrad) {                                            \
+      if (ahead) ITCV_SCIN_K(CI_, true, 1);                     \
+      else ITCV_SCIN_K(CI_, true, 0);                           \
+    } else {                                                    \
+      if (ahead) ITCV_SCIN_K(CI_, false, 1);                    \
+      else ITCV_SCIN_K(CI_, false, 0);                          \
+    }                                                           \
   } while (0)
   if (C == 1) ITCV_SCIN_M(1);
   else if (C == 2) ITCV_SCIN_M(2);
   else ITCV_SCIN_M(3);
+#undef ITCV_SCIN_K
 #undef ITCV_SCIN_M
   ITCV_CHECK_LAUNCH("itcv_conv2d_small_cin_fwd_bf16x3");
   return 0;
