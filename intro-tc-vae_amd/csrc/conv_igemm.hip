@@ -988,34 +988,62 @@ __global__ void split_planes_kernel(const float* __restrict__ x, u32x4* __restri
 }
 
 // wp[kt = cib*KK + tap][plane][kc][Mp] 16-byte chunks of 8 bf16: channels cib*32 + kc*8 + j
-template <int NS>
-__device__ __forceinline__ void pack_weight_bf16s_body(const float* __restrict__ w, u32x4* __restrict__ wp, int Ci, int KK,
-                                                       int for_dgrad, int C, int M, int cpt, int Mp, int blk, int nblk) {
-  const size_t total = (size_t)KK * cpt * 4 * Mp;   // one thread per (kt, kc, m)
-  for (size_t i = (size_t)blk * blockDim.x + threadIdx.x; i < total; i += (size_t)nblk * blockDim.x) {
-    const int m = (int)(i % Mp);
-    const size_t r = i / Mp;
-    const int kc = (int)(r & 3), kt = (int)(r >> 2);
-    const int cib = kt / KK, tap = kt - cib * KK;
+// One block packs a tile of 32 rows (m) x 32 reduction channels (one cib) x all KK taps.  The source is read along
+// its contiguous direction -- forward: the (c, tap) run of row m; data-gradient: the (m, tap) run of channel c -- into
+// LDS, then every thread emits whole 16-byte chunks (8 channels of one (tap, m)) with m fastest across the lanes.
+// Tiles of a layer: (Mp / 32) * cpt, tile = mt32 * cpt + cib.
+template <int NS, int KK>
+__device__ __forceinline__ void pack_weight_bf16s_body(const float* __restrict__ w, u32x4* __restrict__ wp, int Ci,
+                                                       int for_dgrad, int C, int M, int cpt, int Mp, int tile) {
+  constexpr int RUN = 32 * KK, PITCH = RUN + 1;      // odd pitch: the column reads below are conflict free
+  constexpr int ITER = 32 * RUN / 256;               // source elements per thread: all loads are issued before the first use
+  __shared__ float sw[32 * PITCH];
+  const int mt32 = tile / cpt, cib = tile - mt32 * cpt;
+  const int m0 = mt32 * 32, c0 = cib * 32;
+  float ld[ITER];
+#pragma unroll
+  for (int it = 0; it < ITER; ++it) {
+    const int i = it * 256 + threadIdx.x, o = i / RUN, r = i - o * RUN;   // outer row, position inside its contiguous run
+    float v = 0.f;
+    if (for_dgrad) {                                 // outer = channel c0 + o, run = (m0 .. m0+31, tap)
+      const int c = c0 + o, m = m0 + r / KK;
+      if (c < C && m < M) v = w[((size_t)c * Ci + m0) * KK + r];
+    } else {                                         // outer = row m0 + o, run = (c0 .. c0+31, tap)
+      const int m = m0 + o, c = c0 + r / KK;
+      if (m < M && c < C) v = w[((size_t)m * Ci + c0) * KK + r];
+    }
+    ld[it] = v;
+  }
+#pragma unroll
+  for (int it = 0; it < ITER; ++it) {
+    const int i = it * 256 + threadIdx.x, o = i / RUN, r = i - o * RUN;
+    sw[o * PITCH + r] = ld[it];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i0 = 0; i0 < KK * 128; i0 += 256) {
+    const int i = i0 + threadIdx.x;
+    if (i >= KK * 128) break;
+    const int ml = i & 31, kc = (i >> 5) & 3, tap = i >> 7;
     float v[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      const int c = cib * 32 + kc * 8 + j;
-      v[j] = (c < C && m < M) ? (for_dgrad ? w[((size_t)c * Ci + m) * KK + (KK - 1 - tap)]
-                                           : w[((size_t)m * Ci + c) * KK + tap])
-                              : 0.f;
+      const int cl = kc * 8 + j;
+      v[j] = for_dgrad ? sw[cl * PITCH + ml * KK + (KK - 1 - tap)] : sw[ml * PITCH + cl * KK + tap];
     }
     u32x4 pl[NS];
     split8<NS>(v, pl);
+    const int kt = cib * KK + tap;
 #pragma unroll
-    for (int p = 0; p < NS; ++p) wp[(((size_t)kt * NS + p) * 4 + kc) * Mp + m] = pl[p];
+    for (int p = 0; p < NS; ++p) wp[(((size_t)kt * NS + p) * 4 + kc) * Mp + m0 + ml] = pl[p];
   }
 }
 
 template <int NS>
-__global__ void pack_weight_bf16s_kernel(const float* __restrict__ w, u32x4* __restrict__ wp, int Co, int Ci, int KK,
-                                         int for_dgrad, int C, int M, int cpt, int Mp) {
-  pack_weight_bf16s_body<NS>(w, wp, Ci, KK, for_dgrad, C, M, cpt, Mp, blockIdx.x, gridDim.x);
+__global__ __launch_bounds__(256) void pack_weight_bf16s_kernel(const float* __restrict__ w, u32x4* __restrict__ wp, int Co,
+                                                                int Ci, int KK, int for_dgrad, int C, int M, int cpt, int Mp) {
+  if (KK == 9) pack_weight_bf16s_body<NS, 9>(w, wp, Ci, for_dgrad, C, M, cpt, Mp, blockIdx.x);
+  else pack_weight_bf16s_body<NS, 1>(w, wp, Ci, for_dgrad, C, M, cpt, Mp, blockIdx.x);
 }
 
 // Many layers in one launch: a device-resident table of descriptors, every layer owns a contiguous block range.
@@ -1029,11 +1057,23 @@ struct PackDesc {
 static_assert(sizeof(PackDesc) == 56, "PackDesc layout is part of the ABI (itcv_pack_desc_bytes)");
 
 template <int NS>
-__global__ void pack_weights_bf16s_table_kernel(const PackDesc* __restrict__ tab, int n) {
-  int e = 0;
-  while (e + 1 < n && (int)blockIdx.x >= tab[e + 1].block0) ++e;
+__global__ __launch_bounds__(256) void pack_weights_bf16s_table_kernel(const PackDesc* __restrict__ tab, int n) {
+  // the block's layer = the last descriptor whose first block is <= blockIdx.x: all descriptors are looked at in
+  // parallel (a serial walk costs one memory round trip per layer)
+  __shared__ int s_cnt[4];
+  int mine = 0;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) mine += tab[i].block0 <= (int)blockIdx.x ? 1 : 0;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) mine += __shfl_down(mine, off);
+  if ((threadIdx.x & 63) == 0) s_cnt[threadIdx.x >> 6] = mine;
+  __syncthreads();
+  const int e = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3] - 1;
+  __syncthreads();
   const PackDesc d = tab[e];
-  pack_weight_bf16s_body<NS>(d.w, d.wp, d.Ci, d.KK, d.for_dgrad, d.C, d.M, d.cpt, d.Mp, blockIdx.x - d.block0, d.nblocks);
+  if (d.KK == 9)
+    pack_weight_bf16s_body<NS, 9>(d.w, d.wp, d.Ci, d.for_dgrad, d.C, d.M, d.cpt, d.Mp, blockIdx.x - d.block0);
+  else
+    pack_weight_bf16s_body<NS, 1>(d.w, d.wp, d.Ci, d.for_dgrad, d.C, d.M, d.cpt, d.Mp, blockIdx.x - d.block0);
 }
 
 // ------------------------------------------------------------------------------ wgrad
@@ -2294,8 +2334,7 @@ int itcv_conv2d_pack_weight_bf16s(const float* w, void* wp, int Co, int Ci, int 
                "itcv_conv2d_pack_weight_bf16s");
   const int M = for_dgrad ? Ci : Co, C = for_dgrad ? Co : Ci;
   const int bm = M <= 64 ? 64 : 128, Mp = cdiv(M, bm) * bm, cpt = pad32(C) / 32;
-  const size_t total = (size_t)KS * KS * cpt * 4 * Mp;
-  const int blocks = (int)(cdivz(total, 256) < 4096 ? cdivz(total, 256) : 4096);
+  const int blocks = (Mp / 32) * cpt;   // one block per 32 x 32-channel tile
   if (ns == 2)
     hipLaunchKernelGGL(pack_weight_bf16s_kernel<2>, dim3(blocks), dim3(256), 0, S(stream), w, static_cast<u32x4*>(wp),
                        Co, Ci, KS * KS, for_dgrad, C, M, cpt, Mp);
@@ -2314,13 +2353,12 @@ int itcv_conv2d_pack_desc_bf16s(void* host_desc, const float* w, void* wp, int C
                "itcv_conv2d_pack_desc_bf16s");
   const int M = for_dgrad ? Ci : Co, C = for_dgrad ? Co : Ci;
   const int bm = M <= 64 ? 64 : 128, Mp = cdiv(M, bm) * bm, cpt = pad32(C) / 32;
-  const size_t total = (size_t)KS * KS * cpt * 4 * Mp;
   PackDesc d;
   memset(&d, 0, sizeof(d));
   d.w = w, d.wp = static_cast<u32x4*>(wp);
   d.Ci = Ci, d.KK = KS * KS, d.for_dgrad = for_dgrad, d.C = C, d.M = M, d.cpt = cpt, d.Mp = Mp;
   d.block0 = block0;
-  d.nblocks = (int)(cdivz(total, 256) < 1024 ? cdivz(total, 256) : 1024);
+  d.nblocks = (Mp / 32) * cpt;          // one block per 32 x 32-channel tile
   memcpy(host_desc, &d, sizeof(d));
   return d.nblocks;      // > 0: the number of blocks this layer adds to the launch
 }
