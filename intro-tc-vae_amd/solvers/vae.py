@@ -177,10 +177,18 @@ class VAESolver:
             ent["graph"] = torch.cuda.CUDAGraph()
             # thread-local capture mode: the input pipeline's staging thread (hipvae.loader) may allocate pinned memory or
             # issue copies on its own stream while this thread captures.  Data-parallel capture keeps the default (global)
-            # mode: RCCL's watchdog thread relies on it to leave the events of captured collectives alone (in thread-local
-            # mode it queried one and aborted the process: "operation not permitted on an event last recorded in a
-            # capturing stream").
+            # mode and first lets RCCL's watchdog thread retire the collectives of the eager steps: the watchdog polls the
+            # end events of its outstanding work items every 100 ms, and a poll that lands inside the capture -- those
+            # events live on the communicator's stream, which joins the capture -- aborts the process ("operation not
+            # permitted on an event last recorded in a capturing stream" / "... when stream is capturing"; seen as a
+            # one-in-several race before this drain).  Collectives issued during the capture are not handed to the
+            # watchdog (ProcessGroupNCCL skips work enqueued from a capturing stream).
             mode = "thread_local" if ddp.get() is None else "global"
+            if ddp.get() is not None:
+                import os
+                import time
+                # everything is complete (synchronize above): > 3 watchdog periods (ITCV_DDP_DRAIN overrides; diagnostic)
+                time.sleep(float(os.environ.get("ITCV_DDP_DRAIN", "0.35")))
             with torch.cuda.graph(ent["graph"], capture_error_mode=mode):
                 ent["out"] = self._device_step(ent["inp"])
             graphs[key] = ent

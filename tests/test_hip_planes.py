@@ -235,5 +235,7 @@ def test_batchnorm_statistics_from_the_conv_epilogue(HF, shape, groups):
         HF._FUSE_STATS[0] = False
         HF.set_conv_math("fp32")
     a, b = res[True], res[False]
-    assert torch.equal(a[0], b[0])                       # the conv output itself is unchanged
+    # the conv output itself: the statistics-producing launch uses the 32x32x16 MFMA, the plain one 16x16x32 (different
+    # summation order inside a 32-channel group)
+    assert rel_err(a[0], b[0]) < 1e-6
     assert rel_err(a[1], b[1]) < 2e-6 and rel_err(a[2], b[2]) < 1e-6 and rel_err(a[3], b[3]) < 1e-6 and a[4] == b[4] == groups
