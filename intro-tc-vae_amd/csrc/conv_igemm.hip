@@ -791,10 +791,11 @@ struct ConvArgsP {
 #endif
 };
 
-template <int KS, int BM, int BN, int WM, int WN, bool UP2, int NS, int NSTAGE>
+template <int KS, int BM, int BN, int WM, int WN, bool UP2, int NS, int NSTAGE, bool M16 = false>
 __global__ __launch_bounds__(512) void conv_fwd_bf16p_kernel(ConvArgsP a) {
+  static_assert(!M16 || NS == 2, "the 16x16x32 form is written for two planes");
   constexpr int BK = 32, KC = BK / 8, P = KS / 2, KKc = KS * KS;
-  constexpr int WTM = BM / WM, WTN = BN / WN, TM = WTM / 32, TN = WTN / 32;
+  constexpr int WTM = BM / WM, WTN = BN / WN;
   static_assert(WM * WN == 4 && (BN == 128 || BN == 256) && (BM == 64 || BM == 128), "tile / wave layout");
   constexpr int ASZ = NS * KC * BM, BSZ = NS * KC * BN, SSZ = ASZ + BSZ;   // 16-byte chunks per stage
   extern __shared__ u32x4 smem[];
@@ -879,14 +880,17 @@ __global__ __launch_bounds__(512) void conv_fwd_bf16p_kernel(ConvArgsP a) {
   }
 
   // -------------------------------------------------------------------- MFMA waves
-  const int wm = wid / WN, wn = wid % WN, l31 = lane & 31, half = lane >> 5;
-  f32x16 acc[TM][TN];
+  typedef BandMfma<M16> MM;
+  typedef typename MM::acc_t acc_t;
+  constexpr int TS = MM::TS, TMx = WTM / TS, TNx = WTN / TS;
+  const int wm = wid / WN, wn = wid % WN, lr = lane & (TS - 1), kq = lane / TS;
+  acc_t acc[TMx][TNx];
 #pragma unroll
-  for (int i = 0; i < TM; ++i)
+  for (int i = 0; i < TMx; ++i)
 #pragma unroll
-    for (int j = 0; j < TN; ++j)
+    for (int j = 0; j < TNx; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+      for (int r = 0; r < MM::NR; ++r) acc[i][j][r] = 0.f;
   __builtin_amdgcn_s_barrier();
   int slot = 0;
   const long long dbg_c0 = ITCV_ABL(a, 64) ? clock64() : 0, dbg_w0 = ITCV_ABL(a, 64) ? wall_clock64() : 0;
@@ -894,47 +898,80 @@ __global__ __launch_bounds__(512) void conv_fwd_bf16p_kernel(ConvArgsP a) {
     const u32x4* Ab = smem + slot * SSZ;
     const u32x4* Bb = Ab + ASZ;
     if (!ITCV_ABL(a, 8)) {
-      // both k-steps' fragments requested up front, reads interleaved behind the MFMAs (see conv_fwd_bf16p2_kernel)
-      bf16x8 af[2][NS][TM], bfr[2][NS][TN];
+      if constexpr (!M16) {
+        // both k-steps' fragments requested up front, reads interleaved behind the MFMAs (see conv_fwd_bf16p2_kernel)
+        bf16x8 af[2][NS][TMx], bfr[2][NS][TNx];
 #pragma unroll
-      for (int ks = 0; ks < BK / 16; ++ks) {
-        const int kc = ks * 2 + half;
+        for (int ks = 0; ks < BK / 16; ++ks) {
+          const int kc = ks * 2 + kq;
 #pragma unroll
-        for (int pp = 0; pp < NS; ++pp) {
+          for (int pp = 0; pp < NS; ++pp) {
 #pragma unroll
-          for (int i = 0; i < TM; ++i)
-            af[ks][pp][i] = __builtin_bit_cast(bf16x8, Ab[(pp * KC + kc) * BM + wm * WTM + i * 32 + l31]);
+            for (int i = 0; i < TMx; ++i)
+              af[ks][pp][i] = __builtin_bit_cast(bf16x8, Ab[(pp * KC + kc) * BM + wm * WTM + i * 32 + lr]);
 #pragma unroll
-          for (int j = 0; j < TN; ++j)
-            bfr[ks][pp][j] = __builtin_bit_cast(bf16x8, Bb[(pp * KC + kc) * BN + wn * WTN + j * 32 + l31]);
+            for (int j = 0; j < TNx; ++j)
+              bfr[ks][pp][j] = __builtin_bit_cast(bf16x8, Bb[(pp * KC + kc) * BN + wn * WTN + j * 32 + lr]);
+          }
         }
-      }
 #pragma unroll
-      for (int ks = 0; ks < BK / 16; ++ks)
+        for (int ks = 0; ks < BK / 16; ++ks)
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
+          for (int i = 0; i < TMx; ++i)
 #pragma unroll
-          for (int j = 0; j < TN; ++j) {
-            f32x16 c = acc[i][j];
-            if constexpr (NS == 3) {
-              c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks][1][i], bfr[ks][1][j], c, 0, 0, 0);
-              c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks][0][i], bfr[ks][2][j], c, 0, 0, 0);
-              c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks][2][i], bfr[ks][0][j], c, 0, 0, 0);
+            for (int j = 0; j < TNx; ++j) {
+              acc_t c = acc[i][j];
+              if constexpr (NS == 3) {
+                c = MM::mma(af[ks][1][i], bfr[ks][1][j], c);
+                c = MM::mma(af[ks][0][i], bfr[ks][2][j], c);
+                c = MM::mma(af[ks][2][i], bfr[ks][0][j], c);
+              }
+              c = MM::mma(af[ks][0][i], bfr[ks][1][j], c);
+              c = MM::mma(af[ks][1][i], bfr[ks][0][j], c);
+              c = MM::mma(af[ks][0][i], bfr[ks][0][j], c);
+              acc[i][j] = c;
             }
-            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks][0][i], bfr[ks][1][j], c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks][1][i], bfr[ks][0][j], c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks][0][i], bfr[ks][0][j], c, 0, 0, 0);
+        if constexpr (NS == 2) {
+          constexpr int RD = NS * (TMx + TNx), MF = TMx * TNx * 3;
+          __builtin_amdgcn_sched_group_barrier(0x100, RD, 0);
+#pragma unroll
+          for (int r = 0; r < RD; ++r) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+          }
+          __builtin_amdgcn_sched_group_barrier(0x008, 2 * MF - RD, 0);
+        }
+      } else {
+        // 16x16x32: one MFMA per (tile, product) covers the 32-channel K-tile, lane group kq holds chunk kq
+        bf16x8 af[NS][TMx], bfr[NS][TNx];
+#pragma unroll
+        for (int pp = 0; pp < NS; ++pp)
+#pragma unroll
+          for (int j = 0; j < TNx; ++j) bfr[pp][j] = __builtin_bit_cast(bf16x8, Bb[(pp * KC + kq) * BN + wn * WTN + j * 16 + lr]);
+#pragma unroll
+        for (int i = 0; i < TMx; ++i)
+#pragma unroll
+          for (int pp = 0; pp < NS; ++pp) af[pp][i] = __builtin_bit_cast(bf16x8, Ab[(pp * KC + kq) * BM + wm * WTM + i * 16 + lr]);
+#pragma unroll
+        for (int i = 0; i < TMx; ++i)
+#pragma unroll
+          for (int j = 0; j < TNx; ++j) {
+            acc_t c = acc[i][j];
+            c = MM::mma(af[0][i], bfr[1][j], c);
+            c = MM::mma(af[1][i], bfr[0][j], c);
+            c = MM::mma(af[0][i], bfr[0][j], c);
             acc[i][j] = c;
           }
-      if constexpr (NS == 2) {
-        constexpr int RD = NS * (TM + TN), MF = TM * TN * 3;
-        __builtin_amdgcn_sched_group_barrier(0x100, RD, 0);
+        {
+          constexpr int RD0 = NS * TNx + NS * (TMx / 2), RD1 = NS * (TMx - TMx / 2), MF = TMx * TNx * 3;
+          __builtin_amdgcn_sched_group_barrier(0x100, RD0, 0);
 #pragma unroll
-        for (int r = 0; r < RD; ++r) {
-          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+          for (int r = 0; r < RD1; ++r) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+          }
+          __builtin_amdgcn_sched_group_barrier(0x008, MF - RD1, 0);
         }
-        __builtin_amdgcn_sched_group_barrier(0x008, 2 * MF - RD, 0);
       }
     }
     if (++slot == NSTAGE) slot = 0;
@@ -949,16 +986,16 @@ __global__ __launch_bounds__(512) void conv_fwd_bf16p_kernel(ConvArgsP a) {
 
   float* out = a.y + (size_t)sk * a.slab_stride;
 #pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    const int nn = n0 + wn * WTN + j * 32 + l31;
+  for (int j = 0; j < TNx; ++j) {
+    const int nn = n0 + wn * WTN + j * TS + lr;
     if (nn >= a.N) continue;
     const int b2 = nn / HW, hw2 = nn - b2 * HW;
     const size_t base = (size_t)b2 * a.Co * HW + hw2;
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
+    for (int i = 0; i < TMx; ++i) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = m0 + wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+      for (int r = 0; r < MM::NR; ++r) {
+        const int m = m0 + wm * WTM + i * TS + MM::row(r, kq);
         if (m < a.Co) {
           float v = acc[i][j][r];
           if (a.bias) v += a.bias[m];
@@ -2097,13 +2134,25 @@ template <int KS, int BM, int BN, int WM, int WN, bool UP2, int NS, int NSTAGE>
 static void launch_fwd_p_cfg(const ConvArgsP& a, int splits, hipStream_t st) {
   constexpr size_t lds = (size_t)NSTAGE * NS * 4 * (BM + BN) * 16;
   static_assert(lds <= 160 * 1024, "LDS ring too large");
+  dim3 grid(cdiv(a.nt, 8) * 8 * a.mt, splits), blk(512);
+  if constexpr (NS == 2) {
+    if (band_m16()) {
+      auto k16 = conv_fwd_bf16p_kernel<KS, BM, BN, WM, WN, UP2, NS, NSTAGE, true>;
+      static bool attr16 = false;
+      if (!attr16) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k16), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr16 = true;
+      }
+      launch_timed(k16, grid, blk, lds, st, a);
+      return;
+    }
+  }
   auto kern = conv_fwd_bf16p_kernel<KS, BM, BN, WM, WN, UP2, NS, NSTAGE>;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
-  dim3 grid(cdiv(a.nt, 8) * 8 * a.mt, splits), blk(512);
   launch_timed(kern, grid, blk, lds, st, a);
 }
 template <int KS, int NS, int NSTAGE>
