@@ -17,3 +17,11 @@ rm -rf gpurun_out/ev/prof_c2
 echo "prof c2 done"
 timeout -k 10 600 python bench.py > gpurun_out/ev/r02_bench_c2.json 2> gpurun_out/ev/bench_c2.err
 echo "bench c2 done"
+timeout -k 10 600 python bench.py --config c3 --no-modes > gpurun_out/ev/r02_bench_c3.json 2> gpurun_out/ev/bench_c3.err
+echo "bench c3 done"
+timeout -k 10 600 python bench.py --config c5 --no-modes > gpurun_out/ev/r02_bench_c5.json 2> gpurun_out/ev/bench_c5.err
+echo "bench c5 done"
+timeout -k 10 600 rocprofv3 --kernel-trace --stats -d gpurun_out/ev/prof_c3 -o p -- python3 bench.py --config c3 --no-cpu-baseline --no-modes --steps 6 --warmup 3 > gpurun_out/ev/prof_c3.json 2> gpurun_out/ev/prof_c3.err
+python tools/rocpd_stats.py gpurun_out/ev/prof_c3/p_results.db > gpurun_out/ev/r02_c3_kernel_stats.csv 2> gpurun_out/ev/prof_c3_span.txt
+rm -rf gpurun_out/ev/prof_c3
+echo "prof c3 done"
