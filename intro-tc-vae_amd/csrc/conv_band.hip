@@ -343,14 +343,17 @@ __global__ __launch_bounds__(768) void conv_fwd_bf16p2_kernel(ConvArgsP2 a) {
 // become free (and the weight ring simply wraps to the next tile's first taps), and the MFMA waves' result stores of
 // tile t drain while tile t+1 is multiplied.  Barrier structure, counted waits, K order and arithmetic are those of the
 // one-tile kernel (bit-identical results).
-template <int LOG2W, int BM, bool UP2, int BN, bool M16 = false>
-__global__ __launch_bounds__(768) void conv_fwd_bf16p3_kernel(ConvArgsP2 a) {
+// NMW = 4 (64-row tiles, 16x16x32 form; diagnostic, ITCV_BAND_W4=1): four MFMA waves of a 64x64 block each instead of
+// eight of 64x32 -- a third fewer LDS fragment reads per MFMA (16 per 48 instead of 12 per 24).  Measured SLOWER (64 -> 64
+// @ 64x64: 100.8 -> 110.4 us, same box): with one MFMA wave per SIMD nothing fills the barrier / LDS-latency bubbles.
+template <int LOG2W, int BM, bool UP2, int BN, bool M16 = false, int NMW = 8>
+__global__ __launch_bounds__(64 * (NMW + 4)) void conv_fwd_bf16p3_kernel(ConvArgsP2 a) {
   // BN = 256 pixels per tile for W <= 64 (whole rows); BN = 128 for 128- and 256-wide images: one row, or one half of a
   // row whose band then takes its halo columns from the neighbouring half instead of the zero padding
   constexpr int W = 1 << LOG2W, WB = W < BN ? W : BN, LOG2WB = LOG2W < 7 ? LOG2W : 7, WP = WB + 2, KC = 4, NS = 2;
   static_assert(WB == (1 << LOG2WB) && (BN == 256 || BN == 128), "band width");
-  constexpr int WM = BN == 256 ? BM / 64 : 2, WN = 8 / WM, WTN = BN / WN, TM = BM / (32 * WM), TN = WTN / 32;
-  static_assert(TM >= 1 && TN >= 1 && WTN == 32 * TN, "wave tiling");
+  constexpr int WM = BN == 256 ? BM / 64 : 2, WN = NMW / WM, WTN = BN / WN, TM = BM / (32 * WM), TN = WTN / 32;
+  static_assert(TM >= 1 && TN >= 1 && WTN == 32 * TN && (NMW == 8 || (NMW == 4 && M16)), "wave tiling");
   constexpr int ASZ = NS * KC * BM;
   constexpr int PA = NS * KC * BM / 64 / 4;
   constexpr int G = band_taps_per_stage(BM, BN), NSTG = (9 + G - 1) / G;
@@ -385,9 +388,9 @@ __global__ __launch_bounds__(768) void conv_fwd_bf16p3_kernel(ConvArgsP2 a) {
   tcur = next_tile(tcur);
   if (tcur >= nids) return;
 
-  if (wid >= 8) {
+  if (wid >= NMW) {
     // ------------------------------------------------------------------ loaders
-    const int lw = wid - 8;
+    const int lw = wid - NMW;
     const int Hs = UP2 ? H / 2 : H, Ws = UP2 ? W / 2 : W, HWs = Hs * Ws;
     const int C8 = a.Ci >> 3;
     const u32x4* zero = &g_zero_chunk;
@@ -719,6 +722,15 @@ static int band_persistent_blocks() {   // ITCV_BAND_PERSIST=0: one tile per blo
   return v;
 }
 
+static int band_w4() {   // ITCV_BAND_W4=1: four MFMA waves (64x64 blocks) in the persistent 64-row band kernel; slower, see there
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("ITCV_BAND_W4");
+    v = (e && e[0] == '1') ? 1 : 0;
+  }
+  return v;
+}
+
 template <int LOG2W, int BM, bool UP2>
 static void launch_fwd_p2_cfg(const ConvArgsP2& a, int splits, size_t lds, hipStream_t st) {
   auto kern = conv_fwd_bf16p2_kernel<LOG2W, BM, UP2>;
@@ -731,6 +743,18 @@ static void launch_fwd_p2_cfg(const ConvArgsP2& a, int splits, size_t lds, hipSt
   if (!a.stats && ids > band_persistent_blocks() && band_persistent_blocks() > 0) {
     // more tiles than CUs: persistent blocks (one per CU) that prefetch the next tile's band under the current MFMAs
     if (band_m16()) {
+      if constexpr (BM == 64) {
+        if (band_w4()) {
+          auto pk4 = conv_fwd_bf16p3_kernel<LOG2W, BM, UP2, 256, true, 4>;
+          static size_t pattr4 = 0;
+          if (pattr4 < lds) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pk4), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            pattr4 = lds;
+          }
+          launch_timed(pk4, dim3(band_persistent_blocks(), splits), dim3(512), lds, st, a);
+          return;
+        }
+      }
       auto pk = conv_fwd_bf16p3_kernel<LOG2W, BM, UP2, 256, true>;
       static size_t pattr16 = 0;
       if (pattr16 < lds) {
