@@ -19,9 +19,10 @@ One process per GPU; N>1 shards the batch (weak scaling) with a flat RCCL all-re
 per phase and an all-gather of mu for the full-batch TC estimator; BatchNorm statistics are per rank (throughput
 mode) unless --sync-bn (parity mode).  Rank 0 prints ONE JSON line.  The timed region is bracketed by barrier +
 synchronize on both sides and the maximum over ranks is reported.  N=1 times K hipGraph replays of the whole step.
-N>1 times K eager steps (within 1 % of the captured step at ~950 launches per step); ITCV_DDP_GRAPH=try additionally
-times K replays of the captured data-parallel step (RCCL collectives inside the graph) under a watchdog that falls
-back to the finished eager measurement; "graph_leg" on the line says which happened.
+N>1 times K eager steps and then K replays of the captured data-parallel step (RCCL collectives inside the graph;
+3.5 % faster on a one-rank RCCL group: 16.8 vs 17.4 ms) and reports the faster.  The captured leg runs under a
+watchdog, an exception handler and a SIGABRT hook that all fall back to the finished eager measurement; "graph_leg"
+on the line says which happened (ok / abandoned + reason / skipped); ITCV_DDP_GRAPH=0 skips the attempt.
 
 Extra objects on the line:
   roofline      dominant kernel (an implicit-GEMM conv on the matrix cores): algorithmic FLOP of its launches / their
@@ -376,7 +377,7 @@ def main():
     # progress (ITCV_DDP_GRAPH=0 skips the attempt, =1 uses the graph for the main timed region instead).  The faster
     # of the two executions is the reported one, named in "execution".
     if (ddp_on and not use_graph and not args.no_graph and backend == "nccl"
-            and os.environ.get("ITCV_DDP_GRAPH", "off") == "try"):
+            and os.environ.get("ITCV_DDP_GRAPH", "try") == "try"):
         g_elapsed = _guarded_graph_leg(solver, batches, args, rank, sync, dev, out)
         out["graph_leg"] = {"status": "ok", "ms_per_step": round(g_elapsed / args.steps * 1e3, 3)}
         out["eager_events_off_ms_per_step"] = out["ms_per_step"]
@@ -388,9 +389,8 @@ def main():
                        whole_step_tflops=round(value * wl["gflop"] * 1e-3 / world, 2))
     elif ddp_on:
         out["graph_leg"] = {"status": "skipped" if not use_graph else "main",
-                            "reason": ("opt-in (ITCV_DDP_GRAPH=try): with ~950 launches per step the eager data-parallel step "
-                                       "runs within 1 % of the captured one (one-rank RCCL group: 18.2 vs 18.17 ms)")
-                            if not use_graph else "ITCV_DDP_GRAPH=1"}
+                            "reason": "ITCV_DDP_GRAPH=" + os.environ.get("ITCV_DDP_GRAPH", "") + (" / --no-graph" if args.no_graph else "")
+                            + (" / backend " + backend if backend != "nccl" else "")}
     # ---- N=1 on the metric's workload: the same measurement in the reference's own precision (and bf16x6) ----------
     if world == 1 and not ddp_on and args.config == "c2" and not args.no_modes:
         del solver, batches, m
@@ -456,11 +456,19 @@ def _guarded_graph_leg(solver, batches, args, rank, sync, dev, eager_out):
         sys.stderr.flush()
         os._exit(0)
 
+    # abort() from a native thread (RCCL's watchdog) cannot be caught in Python: the library's SIGABRT hook writes the
+    # same abandoned-leg line and leaves with status 0 (ranks other than 0 leave quietly)
+    from hipvae import abi
+    aline = dict(eager_out)
+    aline["graph_leg"] = {"status": "abandoned", "reason": "abort() during the captured leg (SIGABRT)", "deadline_s": deadline}
+    abi.lib.itcv_on_abort_print(json.dumps(aline).encode() if rank == 0 else b"")
     timer = threading.Timer(deadline, bail, args=(f"no result within {deadline:.0f} s",))
     timer.daemon = True
     timer.start()
     try:
-        fault = os.environ.get("ITCV_BENCH_GRAPH_FAULT")          # test hook: "hang" | "raise"
+        fault = os.environ.get("ITCV_BENCH_GRAPH_FAULT")          # test hook: "hang" | "raise" | "abort"
+        if fault == "abort":
+            os.abort()
         if fault == "hang":
             time.sleep(1e6)
         if fault == "raise":
@@ -488,6 +496,7 @@ def _guarded_graph_leg(solver, batches, args, rank, sync, dev, eager_out):
     if closing:
         time.sleep(1e6)
     timer.cancel()
+    abi.lib.itcv_on_abort_print(None)
     if rank == 0:
         log(f"graph (data-parallel): {args.steps} steps in {g_elapsed:.3f} s")
     return g_elapsed

@@ -41,6 +41,11 @@ int itcv_profile_begin(void);
 int itcv_profile_end(void);
 int itcv_profile_get(int i, int* code, double* flop, float* ms);
 int itcv_profile_clear(void);
+/* Measurement harness (bench.py, N>1): arm (line != NULL) or disarm (NULL) a SIGABRT handler that writes `line` to
+ * stdout and ends the process with status 0.  A failure inside RCCL's watchdog thread while the data-parallel step is
+ * being captured ends in abort(); armed with the finished eager measurement (marked "graph_leg": abandoned) the record
+ * still comes out.  An empty line arms the quiet form (ranks other than 0). */
+int itcv_on_abort_print(const char* line);
 
 /* ---- convolution / linear: implicit GEMM on v_mfma_f32_32x32x2_f32 -------------------
  * Stride 1, square odd kernel KS in {1,3,5}, zero padding KS/2 ("same"), groups 1.
