@@ -9,7 +9,6 @@ timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv 
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/ev/pmc_write -o w -- python3 bench.py $ARGS > gpurun_out/ev/pmc_write.json 2> gpurun_out/ev/pmc_write.err
 python tools/pmc_summary.py $(find gpurun_out/ev/pmc_fetch -name '*counter_collection.csv') $(find gpurun_out/ev/pmc_write -name '*counter_collection.csv') > gpurun_out/ev/r02_pmc_traffic.json 2> gpurun_out/ev/pmc_summary.log
 cp gpurun_out/ev/r02_pmc_traffic.json profiles/r02_pmc_traffic.json
-rm -rf gpurun_out/ev/pmc_fetch gpurun_out/ev/pmc_write
 echo "pmc done"
 timeout -k 10 600 rocprofv3 --kernel-trace --stats -d gpurun_out/ev/prof_c2 -o p -- python3 bench.py --no-cpu-baseline --no-modes > gpurun_out/ev/prof_c2.json 2> gpurun_out/ev/prof_c2.err
 python tools/rocpd_stats.py gpurun_out/ev/prof_c2/p_results.db > gpurun_out/ev/r02_c2_kernel_stats.csv 2> gpurun_out/ev/prof_c2_span.txt

@@ -8,7 +8,6 @@ timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv 
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/ev/pmc_write -o w -- python3 bench.py $ARGS > gpurun_out/ev/pmc_write.json 2> gpurun_out/ev/pmc_write.err
 python tools/pmc_summary.py $(find gpurun_out/ev/pmc_fetch -name '*counter_collection.csv') $(find gpurun_out/ev/pmc_write -name '*counter_collection.csv') > gpurun_out/ev/r02_pmc_traffic.json 2> gpurun_out/ev/pmc_summary.log
 cp gpurun_out/ev/r02_pmc_traffic.json profiles/r02_pmc_traffic.json
-rm -rf gpurun_out/ev/pmc_fetch gpurun_out/ev/pmc_write
 echo "pmc done"
 timeout -k 10 600 python bench.py > gpurun_out/ev/r02_bench_c2.json 2> gpurun_out/ev/bench_c2.err
 echo "bench c2 done"

@@ -18,13 +18,13 @@ from collections import defaultdict
 
 
 def fold(name):
-    m = re.search(r"conv_fwd_bf16p_kernel<(\d+), (\d+), \d+, \d+, \d+, (true|false), (\d+), \d+(?:, (?:true|false))?>", name)
+    m = re.search(r"conv_fwd_bf16p_kernel<(\d+), (\d+), \d+, \d+, \d+, (true|false), (\d+), \d+(?:, [^>]*)?>", name)
     if m:
         return f"conv_fwd_bf16p_kernel<KS={m[1]},BM={m[2]},up2={int(m[3] == 'true')},NS={m[4]}>"
-    m = re.search(r"conv_fwd_bf16p2_kernel<(\d+), (\d+), (true|false)(?:, (?:true|false))?>", name)
+    m = re.search(r"conv_fwd_bf16p2_kernel<(\d+), (\d+), (true|false)(?:, [^>]*)?>", name)
     if m:
         return f"conv_fwd_bf16p2_kernel<LOG2W={m[1]},BM={m[2]},up2={int(m[3] == 'true')},NS=2>"
-    m = re.search(r"conv_fwd_bf16p3_kernel<(\d+), (\d+), (true|false), \d+(?:, (?:true|false))?>", name)
+    m = re.search(r"conv_fwd_bf16p3_kernel<(\d+), (\d+), (true|false), \d+(?:, [^>]*)?>", name)
     if m:
         return f"conv_fwd_bf16p3_kernel<LOG2W={m[1]},BM={m[2]},up2={int(m[3] == 'true')},NS=2>"
     m = re.search(r"conv_wgrad_bf16p_kernel<(\d+), (true|false), (\d+)(?:, \d+)*>", name)
