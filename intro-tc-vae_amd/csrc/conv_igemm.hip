@@ -2398,8 +2398,10 @@ size_t itcv_pack_desc_bytes(void) { return sizeof(PackDesc); }
 
 int itcv_conv2d_pack_desc_bf16s(void* host_desc, const float* w, void* wp, int Co, int Ci, int KS, int for_dgrad,
                                 int ns, int block0) {
-  ITCV_REQUIRE(host_desc && w && wp && Co > 0 && Ci > 0 && (KS == 1 || KS == 3) && (ns == 2 || ns == 3) && block0 >= 0,
-               "itcv_conv2d_pack_desc_bf16s");
+  if (!(host_desc && w && wp && Co > 0 && Ci > 0 && (KS == 1 || KS == 3) && (ns == 2 || ns == 3) && block0 >= 0)) {
+    fail("%s: bad argument (pointers, Co/Ci > 0, KS in {1,3}, ns in {2,3}, block0 >= 0)", "itcv_conv2d_pack_desc_bf16s");
+    return -1;     // the success value is a block count
+  }
   const int M = for_dgrad ? Ci : Co, C = for_dgrad ? Co : Ci;
   const int bm = M <= 64 ? 64 : 128, Mp = cdiv(M, bm) * bm, cpt = pad32(C) / 32;
   PackDesc d;

@@ -145,3 +145,31 @@ def test_conv_expand_identity_quirk():
     assert "encoder.main.res_in_2.conv_expand.weight" not in keys      # conv_block(cc, cc): the same object
     r = models.SoftIntroVAE(arch="res", cdim=3, zdim=4, channels=parsed, image_size=16)
     assert "encoder.main.res_in_4.conv_expand.weight" not in r.state_dict()
+
+
+def test_abort_hook_prints_the_prepared_line():
+    """bench.py's last-words hook (itcv_on_abort_print): armed, abort() from any thread writes the prepared line to stdout
+    and the process leaves with status 0; disarmed, abort() is the default SIGABRT again; the pack-descriptor queries
+    answer without a GPU."""
+    import subprocess
+    import sys
+    pre = ("import sys, os, ctypes\nsys.path.insert(0, %r)\nfrom hipvae import abi\n"
+           % os.path.join(ROOT, "intro-tc-vae_amd"))
+    armed = subprocess.run([sys.executable, "-c", pre + "abi.lib.itcv_on_abort_print(b'{\"x\": 1}')\n"
+                            "import threading\nt = threading.Thread(target=os.abort)\nt.start()\nt.join()\n"],
+                           capture_output=True, text=True, timeout=120)
+    assert armed.returncode == 0 and armed.stdout == '{"x": 1}\n'
+    quiet = subprocess.run([sys.executable, "-c", pre + "abi.lib.itcv_on_abort_print(b'')\nos.abort()\n"],
+                           capture_output=True, text=True, timeout=120)
+    assert quiet.returncode == 0 and quiet.stdout == ""
+    off = subprocess.run([sys.executable, "-c", pre + "abi.lib.itcv_on_abort_print(b'x')\n"
+                          "abi.lib.itcv_on_abort_print(None)\nos.abort()\n"], capture_output=True, text=True, timeout=120)
+    assert off.returncode == -6 and off.stdout == ""
+    from hipvae import abi
+    assert abi.lib.itcv_pack_desc_bytes() == 56
+    buf = (ctypes.c_uint8 * 56)()
+    # 512 -> 512 3x3 forward: (512 / 32 row tiles) x (512 / 32 channel groups) blocks; bad arguments give -1
+    assert abi.lib.itcv_conv2d_pack_desc_bf16s(ctypes.byref(buf), 1 << 20, 1 << 21, 512, 512, 3, 0, 2, 7) == 16 * 16
+    assert abi.lib.itcv_conv2d_pack_desc_bf16s(ctypes.byref(buf), 1 << 20, 1 << 21, 136, 64, 3, 1, 2, 0) == (64 // 32) * (160 // 32)
+    assert abi.lib.itcv_conv2d_pack_desc_bf16s(ctypes.byref(buf), None, None, 512, 512, 3, 0, 2, 0) == -1
+    assert "itcv_conv2d_pack_desc_bf16s" in abi.last_error()
