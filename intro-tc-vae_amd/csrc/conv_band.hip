@@ -346,12 +346,14 @@ __global__ __launch_bounds__(768) void conv_fwd_bf16p2_kernel(ConvArgsP2 a) {
 // NMW = 4 (64-row tiles, 16x16x32 form; diagnostic, ITCV_BAND_W4=1): four MFMA waves of a 64x64 block each instead of
 // eight of 64x32 -- a third fewer LDS fragment reads per MFMA (16 per 48 instead of 12 per 24).  Measured SLOWER (64 -> 64
 // @ 64x64: 100.8 -> 110.4 us, same box): with one MFMA wave per SIMD nothing fills the barrier / LDS-latency bubbles.
-template <int LOG2W, int BM, bool UP2, int BN, bool M16 = false, int NMW = 8>
+// ROWS2 (128- and 256-wide images): the 128-pixel tile is 2 rows x 64 columns instead of (half of) one row -- the band is
+// 4 x 66 chunks per plane row instead of 3 x 130, a third less ingest per tile.
+template <int LOG2W, int BM, bool UP2, int BN, bool M16 = false, int NMW = 8, bool ROWS2 = false>
 __global__ __launch_bounds__(64 * (NMW + 4)) void conv_fwd_bf16p3_kernel(ConvArgsP2 a) {
   // BN = 256 pixels per tile for W <= 64 (whole rows); BN = 128 for 128- and 256-wide images: one row, or one half of a
   // row whose band then takes its halo columns from the neighbouring half instead of the zero padding
-  constexpr int W = 1 << LOG2W, WB = W < BN ? W : BN, LOG2WB = LOG2W < 7 ? LOG2W : 7, WP = WB + 2, KC = 4, NS = 2;
-  static_assert(WB == (1 << LOG2WB) && (BN == 256 || BN == 128), "band width");
+  constexpr int W = 1 << LOG2W, WB = ROWS2 ? 64 : (W < BN ? W : BN), LOG2WB = ROWS2 ? 6 : (LOG2W < 7 ? LOG2W : 7), WP = WB + 2, KC = 4, NS = 2;
+  static_assert(WB == (1 << LOG2WB) && (BN == 256 || BN == 128) && (!ROWS2 || (BN == 128 && LOG2W >= 7)), "band width");
   constexpr int WM = BN == 256 ? BM / 64 : 2, WN = NMW / WM, WTN = BN / WN, TM = BM / (32 * WM), TN = WTN / 32;
   static_assert(TM >= 1 && TN >= 1 && WTN == 32 * TN && (NMW == 8 || (NMW == 4 && M16)), "wave tiling");
   constexpr int ASZ = NS * KC * BM;
@@ -384,6 +386,17 @@ __global__ __launch_bounds__(64 * (NMW + 4)) void conv_fwd_bf16p3_kernel(ConvArg
     while (id < nids && tile_n_of(id) >= a.nt) id += stride;
     return id;
   };
+  // first (batch x height) row and first column of N tile tn
+  auto tile_origin = [&](int tn, int& R0, int& col0) {
+    if constexpr (ROWS2) {
+      constexpr int CBS = W / 64;
+      const int rp = tn / CBS;
+      R0 = 2 * rp, col0 = 64 * (tn - rp * CBS);
+    } else {
+      const int pix0 = tn * BN;
+      R0 = pix0 >> LOG2W, col0 = pix0 & (W - 1);           // col0 != 0 only for W > BN
+    }
+  };
   int tcur = (int)blockIdx.x - stride;
   tcur = next_tile(tcur);
   if (tcur >= nids) return;
@@ -398,7 +411,8 @@ __global__ __launch_bounds__(64 * (NMW + 4)) void conv_fwd_bf16p3_kernel(ConvArg
     long long soff[8], soff_n[8];
     uint32_t vmask = 0, vmask_n = 0;
     auto band_offsets = [&](int id, long long (&so)[8], uint32_t& vm) {
-      const int pix0 = tile_n_of(id) * BN, R0 = pix0 >> LOG2W, col0 = pix0 & (W - 1);   // col0 != 0 only for W > BN
+      int R0, col0;
+      tile_origin(tile_n_of(id), R0, col0);
       vm = 0;
 #pragma unroll
       for (int qq = 0; qq < 8; ++qq) {
@@ -628,10 +642,13 @@ __global__ __launch_bounds__(64 * (NMW + 4)) void conv_fwd_bf16p3_kernel(ConvArg
     }
     // result of this tile: plain stores, left to drain under the next tile's MFMAs
     const int m0 = tile_m_of(tcur) * BM, n0 = tile_n_of(tcur) * BN;
+    int R0e = 0, col0e = 0;
+    if constexpr (ROWS2) tile_origin(tile_n_of(tcur), R0e, col0e);
     float* out = a.y + (size_t)sk * a.slab_stride;
 #pragma unroll
     for (int j = 0; j < TNx; ++j) {
-      const int nn = n0 + wn * WTN + j * TS + lr;
+      const int nl = wn * WTN + j * TS + lr;
+      const int nn = ROWS2 ? (R0e + (nl >> 6)) * W + col0e + (nl & 63) : n0 + nl;   // global pixel index b*HW + h*W + w
       if (nn >= a.N) continue;
       const int b2 = nn / HW, hw2 = nn - b2 * HW;
       const size_t base = (size_t)b2 * a.Co * HW + hw2;
@@ -672,7 +689,13 @@ FwdPlanP2 plan_fwd_p2(int B, int Ci, int H, int W, int Co, int KS, int ns) {
     enabled = (e && e[0] == '0') ? 0 : 1;
   }
   if (!enabled) return p;
-  const int WBh = W < p.bn ? W : p.bn, NR = p.bn / WBh;
+  static int rows2 = -1;   // ITCV_BAND_ROWS2=0: one (half) row per 128-pixel tile of a wide image (diagnostic)
+  if (rows2 < 0) {
+    const char* e = getenv("ITCV_BAND_ROWS2");
+    rows2 = (e && e[0] == '0') ? 0 : 1;
+  }
+  p.rows2 = (lw > 6 && H >= 2 && rows2) ? 1 : 0;
+  const int WBh = p.rows2 ? 64 : (W < p.bn ? W : p.bn), NR = p.bn / WBh;
   p.SR = NR < H ? NR : H;
   p.NSEG = NR / p.SR;
   p.NP = p.NSEG * (p.SR + 2) * (WBh + 2);
@@ -798,35 +821,35 @@ static void launch_fwd_p2_w(const ConvArgsP2& a, int bm, int up2, int splits, si
 }
 
 // 128- / 256-wide images: the persistent kernel with 128-pixel tiles
-template <int LOG2W, int BM, bool UP2>
-static void launch_fwd_p3_wide_cfg(const ConvArgsP2& a, int splits, size_t lds, hipStream_t st) {
-  auto pk = conv_fwd_bf16p3_kernel<LOG2W, BM, UP2, 128>;
+template <int LOG2W, int BM, bool UP2, bool M16, bool ROWS2>
+static void launch_fwd_p3_wide_k(const ConvArgsP2& a, int splits, size_t lds, hipStream_t st) {
+  auto pk = conv_fwd_bf16p3_kernel<LOG2W, BM, UP2, 128, M16, 8, ROWS2>;
   static size_t pattr = 0;
   if (pattr < lds) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pk), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     pattr = lds;
   }
   const int ids = cdiv(a.nt, 8) * 8 * a.mt, nb = band_persistent_blocks() > 0 ? band_persistent_blocks() : 256;
-  if (band_m16()) {
-    auto pk16 = conv_fwd_bf16p3_kernel<LOG2W, BM, UP2, 128, true>;
-    static size_t pattr16 = 0;
-    if (pattr16 < lds) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pk16), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      pattr16 = lds;
-    }
-    launch_timed(pk16, dim3(ids < nb ? ids : nb, splits), dim3(768), lds, st, a);
-    return;
-  }
   launch_timed(pk, dim3(ids < nb ? ids : nb, splits), dim3(768), lds, st, a);
 }
-template <int LOG2W>
-static void launch_fwd_p3_wide(const ConvArgsP2& a, int bm, int up2, int splits, size_t lds, hipStream_t st) {
-  if (bm == 64) {
-    if (up2) launch_fwd_p3_wide_cfg<LOG2W, 64, true>(a, splits, lds, st);
-    else launch_fwd_p3_wide_cfg<LOG2W, 64, false>(a, splits, lds, st);
+template <int LOG2W, int BM, bool UP2>
+static void launch_fwd_p3_wide_cfg(const ConvArgsP2& a, int splits, size_t lds, int rows2, hipStream_t st) {
+  if (band_m16()) {
+    if (rows2) launch_fwd_p3_wide_k<LOG2W, BM, UP2, true, true>(a, splits, lds, st);
+    else launch_fwd_p3_wide_k<LOG2W, BM, UP2, true, false>(a, splits, lds, st);
   } else {
-    if (up2) launch_fwd_p3_wide_cfg<LOG2W, 128, true>(a, splits, lds, st);
-    else launch_fwd_p3_wide_cfg<LOG2W, 128, false>(a, splits, lds, st);
+    if (rows2) launch_fwd_p3_wide_k<LOG2W, BM, UP2, false, true>(a, splits, lds, st);
+    else launch_fwd_p3_wide_k<LOG2W, BM, UP2, false, false>(a, splits, lds, st);
+  }
+}
+template <int LOG2W>
+static void launch_fwd_p3_wide(const ConvArgsP2& a, int bm, int up2, int splits, size_t lds, int rows2, hipStream_t st) {
+  if (bm == 64) {
+    if (up2) launch_fwd_p3_wide_cfg<LOG2W, 64, true>(a, splits, lds, rows2, st);
+    else launch_fwd_p3_wide_cfg<LOG2W, 64, false>(a, splits, lds, rows2, st);
+  } else {
+    if (up2) launch_fwd_p3_wide_cfg<LOG2W, 128, true>(a, splits, lds, rows2, st);
+    else launch_fwd_p3_wide_cfg<LOG2W, 128, false>(a, splits, lds, rows2, st);
   }
 }
 
@@ -837,8 +860,8 @@ bool band_is_persistent(const ConvArgsP2& a, const FwdPlanP2& p) {
 
 void launch_fwd_p2(const ConvArgsP2& a, const FwdPlanP2& p, int W, int up2, hipStream_t st) {
   if (p.bn == 128) {
-    if (log2_exact(W) == 7) launch_fwd_p3_wide<7>(a, p.bm, up2, p.splits, p.lds, st);
-    else launch_fwd_p3_wide<8>(a, p.bm, up2, p.splits, p.lds, st);
+    if (log2_exact(W) == 7) launch_fwd_p3_wide<7>(a, p.bm, up2, p.splits, p.lds, p.rows2, st);
+    else launch_fwd_p3_wide<8>(a, p.bm, up2, p.splits, p.lds, p.rows2, st);
     return;
   }
   switch (log2_exact(W)) {

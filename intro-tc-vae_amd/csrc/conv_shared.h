@@ -117,6 +117,7 @@ inline int band_m16() {
 
 struct FwdPlanP2 {
   int ok, bm, bn, mt, nt, cpt, splits, cps, SR, NSEG, NP, NPC, PXB;
+  int rows2;   // wide images: the 128-pixel tile is 2 rows x 64 columns
   size_t lds;
 };
 
