@@ -304,6 +304,54 @@ def test_graph_replay_equals_eager():
     assert float((out["eager_w"] - out["graph_w"]).abs().max()) < 1e-6
 
 
+def test_full_size_c2_step_properties():
+    """BASELINE configs[1] at its full size (64x64x3, z=128, channels (64,128,256,512), batch 64, bf16x3 -- the bench
+    line's workload), where the CPU oracle takes minutes per step: size-independent properties instead.  (a) The same
+    three steps issued as 7 batched passes (persistent band kernels over 2048 tiles, no split-K) and as 13 passes one by
+    one (64-image launches: one-tile kernels, split-K on the 8x8 / 16x16 layers) agree -- two different sets of launch
+    shapes for every conv, BatchNorm and weight-gradient layer; (b) hipGraph replays reproduce the eager trajectory;
+    (c) every returned scalar is finite and the reconstruction loss falls over the steps."""
+    import models
+    torch.manual_seed(11)
+    init = models.SoftIntroVAE(arch="conv", **C2).state_dict()
+    hp = [0.5, 0.75, 512.0, 1e-8, 100.0, 2e-4, 10000]
+    g = torch.Generator().manual_seed(21)
+    xs = [torch.rand(64, 3, 64, 64, generator=g).to(dev()) for _ in range(6)]
+
+    def run(batched, graph, nsteps):
+        model = models.SoftIntroVAE(arch="conv", **C2)
+        model.load_state_dict(init)
+        model = model.to(dev()).train()
+        solver = make_solver("intro_tc", model, hp, math="bf16x3")
+        solver.batch_size = 64
+        solver.batch_passes = batched
+        if graph:
+            solver.enable_graph()
+        torch.cuda.manual_seed(77)                       # the step draws its noise from the device generator
+        res = [solver.train_step(xs[i], i) for i in range(nsteps)]
+        if graph:
+            assert solver._graph is not None
+        return res, torch.cat([p.detach().reshape(-1) for p in model.parameters()]).cpu()
+
+    (rb, wb), (ru, wu) = run(True, False, 3), run(False, False, 3)
+    # step 0 (identical weights): every scalar to 1e-5 (measured 3e-7 / 1e-6, the clip norm L2 1.5e-5 -> 1e-4).  From
+    # step 1 on the two runs are different trajectories: Adam turns the sign of a near-zero gradient into +-lr, and the
+    # exp(-2*scale*(rec + 512*kl)) terms of loss_enc amplify that (measured 8e-4 / 2e-3 at steps 1 / 2, 1.2e-3 / 5e-3 in
+    # exact fp32 mode as well): held to 2e-2 there, and the weights through the size of the update (3 steps x 2e-4)
+    for i, (a, b) in enumerate(zip(rb, ru)):
+        for k in a:
+            tol = (1e-4 if k == "L2" else 1e-5) if i == 0 else 2e-2
+            assert a[k] == a[k] and abs(a[k] - b[k]) <= tol * abs(b[k]) + 1e-7, (i, k, a[k], b[k])
+    assert float((wb - wu).abs().max()) <= 2.05 * 3 * 2e-4
+    assert float((wb - wu).abs().mean()) < 1.5e-4       # a quarter of the largest possible total update
+    assert rb[2]["loss_rec"] < rb[0]["loss_rec"]
+    (rg, wg), (re_, we) = run(True, True, 6), run(True, False, 6)
+    for a, b in zip(rg, re_):
+        for k in a:
+            assert abs(a[k] - b[k]) <= 1e-5 * abs(b[k]) + 1e-9, (k, a[k], b[k])
+    assert float((wg - we).abs().max()) < 1e-6
+
+
 class StubWriter:
     """Stands in for torch.utils.tensorboard.SummaryWriter: records every call the solvers make."""
 
