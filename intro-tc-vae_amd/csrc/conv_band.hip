@@ -358,7 +358,7 @@ __global__ __launch_bounds__(64 * (NMW + 4)) void conv_fwd_bf16p3_kernel(ConvArg
   static_assert(TM >= 1 && TN >= 1 && WTN == 32 * TN && (NMW == 8 || (NMW == 4 && M16)), "wave tiling");
   constexpr int ASZ = NS * KC * BM;
   constexpr int PA = NS * KC * BM / 64 / 4;
-  constexpr int G = band_taps_per_stage(BM, BN), NSTG = (9 + G - 1) / G;
+  constexpr int G = band_taps_per_stage(BM, BN, LOG2W), NSTG = (9 + G - 1) / G;
   extern __shared__ u32x4 smem[];
 
   const int t = threadIdx.x, lane = t & 63;
@@ -681,8 +681,19 @@ FwdPlanP2 plan_fwd_p2(int B, int Ci, int H, int W, int Co, int KS, int ns) {
   FwdPlanP2 p;
   memset(&p, 0, sizeof(p));
   const int lw = log2_exact(W), lh = log2_exact(H);
-  if (KS != 3 || ns != 2 || lw < 3 || lw > 8 || lh < 0 || Ci % 32 || Co < 33) return p;
-  p.bn = lw > 6 ? 128 : 256;     // 128- and 256-wide images: 128-pixel tiles (one row / half a row), persistent kernel only
+  // ITCV_BAND_W4PX=1 (diagnostic): the band form for 4-pixel-wide images (the 4x4 layers).  Built, verified and measured
+  // no faster than the 128-pixel planes kernel (512 -> 512 @ 4x4 x 128 images: 302 vs 312 TFLOP/s): those launches are
+  // bound by streaming 9.4 MB of weights per 128-pixel tile, not by the 9x activation re-reads the band form removes.
+  static int w4 = -1;
+  if (w4 < 0) {
+    const char* e = getenv("ITCV_BAND_W4PX");
+    w4 = (e && e[0] == '1') ? 1 : 0;
+  }
+  if (KS != 3 || ns != 2 || lw < (w4 ? 2 : 3) || lw > 8 || lh < 0 || Ci % 32 || Co < 33) return p;
+  // 128- and 256-wide images: 128-pixel tiles (two rows x 64 columns), persistent kernel only.  4-wide images (the 4x4
+  // layers): 128-pixel tiles = 8 images of 4 rows, each with its own 6x6 halo'd band segment -- the band form reads
+  // 2.25 chunks per pixel and group where the 128-pixel planes kernel fetches every tap separately (9)
+  p.bn = (lw > 6 || lw == 2) ? 128 : 256;
   static int enabled = -1;
   if (enabled < 0) {
     const char* e = getenv("ITCV_BF16P2");
@@ -706,7 +717,7 @@ FwdPlanP2 plan_fwd_p2(int B, int Ci, int H, int W, int Co, int KS, int ns) {
   p.bm = Co <= 64 ? 64 : 128;
   // mid-sized layers: 64-row tiles when that fills the chip without split-K and 128-row tiles would not
   if (p.bm == 128 && cdiv(Co, 128) * p.nt < 192 && cdiv(Co, 64) * p.nt >= 192 && p2_bm64_mid()) p.bm = 64;
-  p.lds = ((size_t)3 * band_taps_per_stage(p.bm, p.bn) * 2 * 4 * p.bm + (size_t)2 * 2 * 4 * p.PXB) * 16;   // [3][G] weight ring + 2 bands
+  p.lds = ((size_t)3 * band_taps_per_stage(p.bm, p.bn, lw) * 2 * 4 * p.bm + (size_t)2 * 2 * 4 * p.PXB) * 16;   // [3][G] weight ring + 2 bands
   const size_t stage_bytes = p.bn == 256 ? (size_t)p.bm * (256 + 4) * sizeof(float) : 0;   // the staged epilogue's tile reuses the allocation
   if (p.lds < stage_bytes) p.lds = stage_bytes;
   if (p.lds > 160 * 1024) return p;
@@ -834,13 +845,15 @@ static void launch_fwd_p3_wide_k(const ConvArgsP2& a, int splits, size_t lds, hi
 }
 template <int LOG2W, int BM, bool UP2>
 static void launch_fwd_p3_wide_cfg(const ConvArgsP2& a, int splits, size_t lds, int rows2, hipStream_t st) {
-  if (band_m16()) {
-    if (rows2) launch_fwd_p3_wide_k<LOG2W, BM, UP2, true, true>(a, splits, lds, st);
-    else launch_fwd_p3_wide_k<LOG2W, BM, UP2, true, false>(a, splits, lds, st);
-  } else {
-    if (rows2) launch_fwd_p3_wide_k<LOG2W, BM, UP2, false, true>(a, splits, lds, st);
-    else launch_fwd_p3_wide_k<LOG2W, BM, UP2, false, false>(a, splits, lds, st);
+  if constexpr (LOG2W >= 7) {
+    if (rows2) {
+      if (band_m16()) launch_fwd_p3_wide_k<LOG2W, BM, UP2, true, true>(a, splits, lds, st);
+      else launch_fwd_p3_wide_k<LOG2W, BM, UP2, false, true>(a, splits, lds, st);
+      return;
+    }
   }
+  if (band_m16()) launch_fwd_p3_wide_k<LOG2W, BM, UP2, true, false>(a, splits, lds, st);
+  else launch_fwd_p3_wide_k<LOG2W, BM, UP2, false, false>(a, splits, lds, st);
 }
 template <int LOG2W>
 static void launch_fwd_p3_wide(const ConvArgsP2& a, int bm, int up2, int splits, size_t lds, int rows2, hipStream_t st) {
@@ -861,6 +874,7 @@ bool band_is_persistent(const ConvArgsP2& a, const FwdPlanP2& p) {
 void launch_fwd_p2(const ConvArgsP2& a, const FwdPlanP2& p, int W, int up2, hipStream_t st) {
   if (p.bn == 128) {
     if (log2_exact(W) == 7) launch_fwd_p3_wide<7>(a, p.bm, up2, p.splits, p.lds, p.rows2, st);
+    else if (log2_exact(W) == 2) launch_fwd_p3_wide<2>(a, p.bm, up2, p.splits, p.lds, 0, st);
     else launch_fwd_p3_wide<8>(a, p.bm, up2, p.splits, p.lds, p.rows2, st);
     return;
   }

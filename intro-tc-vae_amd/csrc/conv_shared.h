@@ -76,7 +76,10 @@ struct ConvArgsP2 {
 };
 
 // taps (K-tiles) per barrier stage of the band kernels: tiles with little MFMA work per tap take two
-__host__ __device__ constexpr int band_taps_per_stage(int bm, int bn) { return (bm == 64 || bn == 128) ? 2 : 1; }
+// (the 4-pixel-wide 128-row form keeps one tap per stage: two would not fit LDS next to its 8-segment bands)
+__host__ __device__ constexpr int band_taps_per_stage(int bm, int bn, int lw) {
+  return (bm == 64 || (bn == 128 && lw != 2)) ? 2 : 1;
+}
 
 // MFMA shape of the band kernels' inner product.  The chip lowers its clock under dense bf16 MFMA loops and holds a
 // higher one on v_mfma_f32_16x16x32_bf16 than on 32x32x16 at equal cycles per FLOP (MI355X_MICROARCH.md, DVFS give-back
