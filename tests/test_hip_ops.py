@@ -59,6 +59,8 @@ SPLIT_CASES = [  # shapes the split-bf16 kernels cover (Ci % 32 == 0, Co > 32, K
     (4, 128, 4, 4, 256, 3, False), (5, 64, 1, 1, 70, 1, False), (2, 64, 16, 16, 48, 3, True), (2, 512, 4, 4, 64, 3, False),
     # 128- and 256-wide images (BASELINE configs[2] / [4]): the weight gradient walks 64-column segments of a row
     (2, 32, 8, 128, 40, 3, False), (1, 64, 4, 256, 64, 3, False), (1, 32, 16, 256, 72, 3, True), (3, 64, 2, 128, 128, 3, True),
+    # weight-heavy 4x4 layers at the benchmark's pixel counts: split-K over the 9 * Ci / 32 K-tiles
+    (32, 512, 4, 4, 256, 3, False), (64, 256, 4, 4, 520, 3, False), (32, 256, 4, 4, 256, 3, True),
 ]
 
 
