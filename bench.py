@@ -20,9 +20,12 @@ per phase and an all-gather of mu for the full-batch TC estimator; BatchNorm sta
 mode) unless --sync-bn (parity mode).  Rank 0 prints ONE JSON line.  The timed region is bracketed by barrier +
 synchronize on both sides and the maximum over ranks is reported.  N=1 times K hipGraph replays of the whole step.
 N>1 times K eager steps and then K replays of the captured data-parallel step (RCCL collectives inside the graph;
-3.5 % faster on a one-rank RCCL group: 16.8 vs 17.4 ms) and reports the faster.  The captured leg runs under a
-watchdog, an exception handler and a SIGABRT hook that all fall back to the finished eager measurement; "graph_leg"
-on the line says which happened (ok / abandoned + reason / skipped); ITCV_DDP_GRAPH=0 skips the attempt.
+3.5 % faster on a one-rank RCCL group: 16.8 vs 17.4 ms) and reports the faster.  Each rank's bench.py is then a
+SUPERVISOR that never touches the GPU: it runs the eager measurement in one child process (`--leg eager`, a complete
+measurement on its own; its failure is this process's failure, same exit status) and the captured leg in a second,
+fresh child (`--leg graph`, own rendezvous port, a deadline).  If that optional leg fails, hangs or aborts, its child
+dies with its own non-zero status and the supervisor prints the eager line with "graph_leg": {"status": "abandoned",
+"reason": ...}; nothing in a GPU-touched process turns a fault into status 0.  ITCV_DDP_GRAPH=0 skips the attempt.
 
 Extra objects on the line:
   roofline      dominant kernel (an implicit-GEMM conv on the matrix cores): algorithmic FLOP of its launches / their
@@ -299,6 +302,9 @@ def main():
                     help="conv GEMM arithmetic: bf16x3 = use_amp=True (the reference's config default), split-bf16 "
                          "MFMA with fp32 accumulate; bf16x6 = fp32-class 3-way split; fp32 = exact fp32 MFMA")
     ap.add_argument("--no-graph", action="store_true", help="time eager launches instead of hipGraph replays (N=1)")
+    ap.add_argument("--leg", choices=["eager", "graph"], default=None,
+                    help="(internal, N>1) run ONE leg of the data-parallel measurement in this process; without it an N>1 "
+                         "invocation supervises the two legs as child processes")
     args = ap.parse_args()
     wl = CONFIGS[args.config]
 
@@ -310,13 +316,16 @@ def main():
     # ITCV_BENCH_BACKEND=gloo (test rigs with fewer GPUs than ranks: ranks share devices, collectives staged on
     # the host) -- the measured configuration is always nccl (= RCCL), one GPU per rank
     backend = os.environ.get("ITCV_BENCH_BACKEND", "nccl")
+    force_ddp = world == 1 and os.environ.get("ITCV_BENCH_FORCE_DDP", "0") == "1"
+    if ((world > 1 or force_ddp) and args.leg is None and not args.no_graph and backend == "nccl"
+            and os.environ.get("ITCV_DDP_GRAPH", "try") == "try"):
+        return _supervise_legs(rank)             # this process never initialises the GPU
     if backend != "nccl":
         local_rank %= max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     # ITCV_BENCH_FORCE_DDP=1 (one-GPU rigs): a group of ONE rank with the data-parallel code paths on, so the step's
     # collectives run through RCCL on the device -- the launch-side cost of the N>1 path without the wire time
-    force_ddp = world == 1 and os.environ.get("ITCV_BENCH_FORCE_DDP", "0") == "1"
     if force_ddp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29541")
@@ -342,6 +351,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if args.leg == "graph":
+        return _graph_leg(wl, args, dev, rank, world, sync)
     # N>1: eager unless ITCV_DDP_GRAPH=1 (RCCL collectives captured in the step graph; hipvae.ddp.graph_capturable)
     ddp_on = ddp.get() is not None
     use_graph = not args.no_graph and (not ddp_on or ddp.graph_capturable())
@@ -371,24 +382,8 @@ def main():
     }
     if m["h2d"] is not None:
         out["host_fed"] = m["h2d"]
-    # ---- N>1 over RCCL: the same K steps once more with the data-parallel step captured into the step hipGraph ----
-    # The eager measurement above is complete and stays the fallback: a watchdog prints it -- with
-    # "graph_leg": {"status": "abandoned", "reason": ...} -- and ends the process if the captured leg raises or makes no
-    # progress (ITCV_DDP_GRAPH=0 skips the attempt, =1 uses the graph for the main timed region instead).  The faster
-    # of the two executions is the reported one, named in "execution".
-    if (ddp_on and not use_graph and not args.no_graph and backend == "nccl"
-            and os.environ.get("ITCV_DDP_GRAPH", "try") == "try"):
-        g_elapsed = _guarded_graph_leg(solver, batches, args, rank, sync, dev, out)
-        out["graph_leg"] = {"status": "ok", "ms_per_step": round(g_elapsed / args.steps * 1e3, 3)}
-        out["eager_events_off_ms_per_step"] = out["ms_per_step"]
-        out["graph_ms_per_step"] = round(g_elapsed / args.steps * 1e3, 3)
-        if g_elapsed < elapsed:
-            value = images / g_elapsed
-            out.update(value=round(value, 2), ms_per_step=out["graph_ms_per_step"],
-                       execution="hipGraph replay (whole data-parallel step, RCCL collectives included, = one graph per rank)",
-                       whole_step_tflops=round(value * wl["gflop"] * 1e-3 / world, 2))
-    elif ddp_on:
-        out["graph_leg"] = {"status": "skipped" if not use_graph else "main",
+    if ddp_on:
+        out["graph_leg"] = {"status": "main" if use_graph else ("pending" if args.leg == "eager" else "skipped"),
                             "reason": "ITCV_DDP_GRAPH=" + os.environ.get("ITCV_DDP_GRAPH", "") + (" / --no-graph" if args.no_graph else "")
                             + (" / backend " + backend if backend != "nccl" else "")}
     # ---- N=1 on the metric's workload: the same measurement in the reference's own precision (and bf16x6) ----------
@@ -433,73 +428,91 @@ def _stdout_to_stderr():
         os.close(saved)
 
 
-def _guarded_graph_leg(solver, batches, args, rank, sync, dev, eager_out):
-    """Capture the data-parallel step and time K replays (max over ranks).  Never returns on failure: on an exception
-    or when the deadline passes (a rank stuck in a collective), rank 0 prints the finished eager measurement
-    (``eager_out``) with "graph_leg": {"status": "abandoned", "reason": ...} added -- so the record shows that the
-    captured leg did not complete and why -- and every rank that notices ends its process.  Nothing is re-executed and
-    no process is replaced: the eager numbers were complete before this leg started."""
-    import threading
-    deadline = float(os.environ.get("ITCV_BENCH_GRAPH_DEADLINE", "90"))
-    lock, state = threading.Lock(), {"closed": False}
-
-    def bail(reason):
-        with lock:
-            if state["closed"]:
-                return
-            state["closed"] = True
-        if rank == 0:
-            log(f"captured data-parallel leg abandoned ({reason}); reporting the eager measurement")
-            line = dict(eager_out)
-            line["graph_leg"] = {"status": "abandoned", "reason": str(reason)[:300], "deadline_s": deadline}
-            print(json.dumps(line), flush=True)
-        sys.stderr.flush()
-        os._exit(0)
-
-    # abort() from a native thread (RCCL's watchdog) cannot be caught in Python: the library's SIGABRT hook writes the
-    # same abandoned-leg line and leaves with status 0 (ranks other than 0 leave quietly)
-    from hipvae import abi
-    aline = dict(eager_out)
-    aline["graph_leg"] = {"status": "abandoned", "reason": "abort() during the captured leg (SIGABRT)", "deadline_s": deadline}
-    abi.lib.itcv_on_abort_print(json.dumps(aline).encode() if rank == 0 else b"")
-    timer = threading.Timer(deadline, bail, args=(f"no result within {deadline:.0f} s",))
-    timer.daemon = True
-    timer.start()
-    try:
-        fault = os.environ.get("ITCV_BENCH_GRAPH_FAULT")          # test hook: "hang" | "raise" | "abort"
-        if fault == "abort":
-            os.abort()
-        if fault == "hang":
-            time.sleep(1e6)
-        if fault == "raise":
-            raise RuntimeError("injected fault")
-        os.environ["ITCV_DDP_GRAPH"] = "1"
-        solver.enable_graph()
-        for i in range(5):                      # 3 eager warm-ups, capture + first replay, one more replay
-            solver.train_step(batches[i % len(batches)], 0)
-        if solver._graph is None:
-            raise RuntimeError("the data-parallel step was not captured")
-        sync()
-        t0 = time.perf_counter()
-        for i in range(args.steps):
-            solver.train_step(batches[i % len(batches)], args.warmup + 2 * args.steps + i)
-        sync()
-        t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        g_elapsed = float(t)
-    except BaseException as e:  # noqa: BLE001 -- the eager line must still come out
-        bail(repr(e))
-        time.sleep(1e6)                          # a concurrent bail() is ending the process
-    with lock:
-        closing = state["closed"]
-        state["closed"] = True
-    if closing:
+def _graph_leg(wl, args, dev, rank, world, sync):
+    """`--leg graph` (child process of the supervisor): the data-parallel step captured into one hipGraph per rank, RCCL
+    collectives included; times K replays (max over ranks); rank 0 prints {"graph_elapsed_s": ...}.  Any failure is this
+    process's own failure (non-zero exit status / signal); the supervisor decides what to report."""
+    fault = os.environ.get("ITCV_BENCH_GRAPH_FAULT")          # test hook: "hang" | "raise" | "abort"
+    if fault == "abort":
+        os.abort()
+    if fault == "hang":
         time.sleep(1e6)
-    timer.cancel()
-    abi.lib.itcv_on_abort_print(None)
+    if fault == "raise":
+        raise RuntimeError("injected fault")
+    solver = make_solver(wl, args.math, dev)
+    B, S = wl["batch"], wl["cfg"]["image_size"]
+    g = torch.Generator().manual_seed(1000 + rank)
+    batches = [torch.rand(B, 3, S, S, generator=g).to(dev) for _ in range(4)]
+    solver.enable_graph()
+    for i in range(max(args.warmup, 5)):         # 3 eager warm-ups, capture + first replay, further replays
+        solver.train_step(batches[i % len(batches)], i)
+    if solver._graph is None:
+        raise RuntimeError("the data-parallel step was not captured")
+    sync()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        solver.train_step(batches[i % len(batches)], args.warmup + i)
+    sync()
+    t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
     if rank == 0:
-        log(f"graph (data-parallel): {args.steps} steps in {g_elapsed:.3f} s")
-    return g_elapsed
+        log(f"graph (data-parallel): {args.steps} steps in {float(t):.3f} s")
+        print(json.dumps({"graph_elapsed_s": float(t), "steps": args.steps}), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _supervise_legs(rank):
+    """N>1 (or the one-rank rig ITCV_BENCH_FORCE_DDP=1): run the two legs as child processes of this one, which never
+    initialises the GPU.  Leg 1 (eager) IS the measurement: if it fails, so does this process, with the child's status.
+    Leg 2 (captured) is optional: whatever happens to its process -- exception, abort() in RCCL's watchdog thread, a
+    rank stuck in a collective until the deadline -- rank 0 reports the finished eager line with the reason."""
+    import subprocess
+    me = [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]
+    a = subprocess.run(me + ["--leg", "eager"], stdout=subprocess.PIPE, text=True)
+    lines = [ln for ln in a.stdout.splitlines() if ln.startswith("{")]
+    if a.returncode != 0 or (rank == 0 and not lines):
+        sys.stdout.write(a.stdout)
+        log(f"eager leg failed (status {a.returncode})")
+        sys.exit(a.returncode if a.returncode > 0 else 1)
+    out = json.loads(lines[-1]) if rank == 0 else None
+    env = dict(os.environ)
+    # own rendezvous: a store of this leg's own on the next port (the launcher's agent store still holds the first
+    # leg's communicator keys)
+    env["MASTER_ADDR"] = env.get("MASTER_ADDR", "127.0.0.1")
+    env["MASTER_PORT"] = str(int(env.get("MASTER_PORT", "29541")) + 1)
+    env.pop("TORCHELASTIC_USE_AGENT_STORE", None)
+    env["ITCV_DDP_GRAPH"] = "1"
+    deadline = float(os.environ.get("ITCV_BENCH_GRAPH_DEADLINE", "240"))
+    status, reason, g_elapsed = "abandoned", None, None
+    try:
+        b = subprocess.run(me + ["--leg", "graph"], stdout=subprocess.PIPE, text=True, env=env, timeout=deadline)
+        glines = [ln for ln in b.stdout.splitlines() if ln.startswith("{")]
+        if b.returncode == 0 and (rank != 0 or glines):
+            status = "ok"
+            if rank == 0:
+                g_elapsed = json.loads(glines[-1])["graph_elapsed_s"]
+        else:
+            reason = (f"the captured leg's process ended with status {b.returncode}"
+                      + (" (killed by signal %d)" % -b.returncode if b.returncode < 0 else ""))
+    except subprocess.TimeoutExpired:
+        reason = f"no result within {deadline:.0f} s (process killed)"
+    if rank != 0:
+        return
+    if status == "ok":
+        steps, images = out["steps"], out["config"]["global_batch"] * out["steps"]
+        out["graph_leg"] = {"status": "ok", "ms_per_step": round(g_elapsed / steps * 1e3, 3)}
+        out["eager_events_off_ms_per_step"] = out["ms_per_step"]
+        out["graph_ms_per_step"] = round(g_elapsed / steps * 1e3, 3)
+        if out["graph_ms_per_step"] < out["ms_per_step"]:
+            eager_value, value = out["value"], images / g_elapsed
+            out.update(value=round(value, 2), ms_per_step=out["graph_ms_per_step"],
+                       execution="hipGraph replay (whole data-parallel step, RCCL collectives included, = one graph per rank)",
+                       whole_step_tflops=round(out["whole_step_tflops"] * value / eager_value, 2))
+    else:
+        log(f"captured data-parallel leg abandoned ({reason}); reporting the eager measurement")
+        out["graph_leg"] = {"status": "abandoned", "reason": reason, "deadline_s": deadline}
+    print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

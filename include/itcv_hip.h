@@ -41,11 +41,6 @@ int itcv_profile_begin(void);
 int itcv_profile_end(void);
 int itcv_profile_get(int i, int* code, double* flop, float* ms);
 int itcv_profile_clear(void);
-/* Measurement harness (bench.py, N>1): arm (line != NULL) or disarm (NULL) a SIGABRT handler that writes `line` to
- * stdout and ends the process with status 0.  A failure inside RCCL's watchdog thread while the data-parallel step is
- * being captured ends in abort(); armed with the finished eager measurement (marked "graph_leg": abandoned) the record
- * still comes out.  An empty line arms the quiet form (ranks other than 0). */
-int itcv_on_abort_print(const char* line);
 
 /* ---- convolution / linear: implicit GEMM on v_mfma_f32_32x32x2_f32 -------------------
  * Stride 1, square odd kernel KS in {1,3,5}, zero padding KS/2 ("same"), groups 1.
@@ -303,6 +298,26 @@ int itcv_tc_bwd(const float* g, const float* z, const float* mu_all, const float
 /* solvers/tc.py:104-121: per-sample log q(z|x) (ops.py:24-29 density, own mu/logvar) and log p(z) */
 int itcv_diag_logdensity_rows(const float* z, const float* mu, const float* logvar, float* logq_cx,
                               float* logpz, int B, int D, void* stream);
+/* Materialising forms of the reference's named helpers, for callers that use the pieces one by one
+ * (`from ops import gaussian_log_density, ...`, solvers/tc.py:5-11); the training step uses the fused kernels above.
+ * ops.py:15-21 (eps_density != 0: variance floor 1e-4, straight-through) / ops.py:24-29: out[n0][n1][n2] =
+ * clamp(log N(x; mu, exp(logvar)), min=-50) with the three operands broadcast to dims[3] through element strides
+ * sx/sm/sl[3] (0 = broadcast dimension).  _bwd: elementwise gradients at the broadcast shape, dx (dmu = -dx) and
+ * dlogvar, zero where the clamp is active; the caller sums them over its broadcast dimensions. */
+int itcv_gauss_logdensity_fwd(const float* x, const float* mu, const float* logvar, float* out, const int64_t* dims,
+                              const int64_t* sx, const int64_t* sm, const int64_t* sl, int eps_density, void* stream);
+int itcv_gauss_logdensity_bwd(const float* g, const float* x, const float* mu, const float* logvar, float* dx,
+                              float* dlogvar, const int64_t* dims, const int64_t* sx, const int64_t* sm,
+                              const int64_t* sl, int eps_density, void* stream);
+/* ops.py:104-115 (weighted == 0) / ops.py:92-101 on a materialised lp[B][B][D]: prodm[B], logqz[B]; lse[B][D] and
+ * sjoint[B][B] are kept for _bwd, which returns dlp[B][B][D] for gradients g_prodm[B], g_logqz[B]. */
+int itcv_sampling_fwd(const float* lp, float* prodm, float* logqz, float* lse, float* sjoint, int B, int D,
+                      int64_t dataset_size, int weighted, void* stream);
+int itcv_sampling_bwd(const float* g_prodm, const float* g_logqz, const float* lp, const float* lse,
+                      const float* sjoint, const float* logqz, float* dlp, int B, int D, int64_t dataset_size,
+                      int weighted, void* stream);
+/* ops.py:118-122 for x[m][n] with m == n or m == 1: diag[min(m,n)], off[m][n][n] = x - diag_embed(x) */
+int itcv_on_off_diag(const float* x, float* diag, float* off, int m, int n, void* stream);
 
 /* ---- reconstruction loss (ops.py:188-236) --------------------------------------------- */
 #define ITCV_LOSS_MSE 0

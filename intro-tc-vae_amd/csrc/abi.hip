@@ -1,9 +1,6 @@
 // Library-level entry points of libitcv_hip.so (error reporting, ABI version).
 #include "common.h"
 
-#include <signal.h>
-#include <unistd.h>
-
 #include <vector>
 
 namespace itcv {
@@ -38,40 +35,7 @@ ProfScope::~ProfScope() {
 thread_local hipEvent_t g_prof_start = nullptr, g_prof_stop = nullptr;
 }
 
-namespace itcv {
-// Last words of a measurement process (bench.py, N>1 captured leg): a failure inside RCCL's watchdog thread ends in
-// abort(), which no Python-level handler survives.  Armed, SIGABRT writes the prepared line (the finished eager
-// measurement, marked "graph_leg": abandoned) to stdout with write(2) and leaves with _exit(0).
-static char g_abort_line[65536];
-static size_t g_abort_len = 0;
-static void abort_line_handler(int) {
-  size_t off = 0;
-  while (off < g_abort_len) {
-    const ssize_t r = write(1, g_abort_line + off, g_abort_len - off);
-    if (r <= 0) break;
-    off += (size_t)r;
-  }
-  _exit(0);
-}
-}  // namespace itcv
-
 extern "C" {
-int itcv_on_abort_print(const char* line) {
-  using namespace itcv;
-  if (!line) {                               // disarm
-    g_abort_len = 0;
-    signal(SIGABRT, SIG_DFL);
-    return 0;
-  }
-  const size_t n = strlen(line);
-  if (n + 2 > sizeof(g_abort_line)) return fail("%s: line too long (%lld bytes)", "itcv_on_abort_print", (long long)n);
-  memcpy(g_abort_line, line, n);
-  g_abort_len = n;
-  if (n && g_abort_line[n - 1] != '\n') g_abort_line[g_abort_len++] = '\n';
-  signal(SIGABRT, abort_line_handler);
-  return 0;
-}
-
 int itcv_abi_version(void) { return ITCV_ABI_VERSION; }
 const char* itcv_last_error(void) { return itcv::g_err; }
 

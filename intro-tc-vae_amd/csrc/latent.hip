@@ -315,6 +315,122 @@ __global__ void kl_rows_bwd_kernel(const float* __restrict__ g, const float* __r
   }
 }
 
+// ---- materialising forms of the reference's named helpers (ops.py:15-29, 92-123) ---------------------------
+// The training step never builds the [B,B,D] tensor (kernels above); these serve callers that use the reference's
+// pieces one by one (`from ops import gaussian_log_density, minibatch_stratified_sampling`, solvers/tc.py:5-11).
+struct Bc3 {                  // three operands broadcast to a common [n0][n1][n2] shape: element strides, 0 = broadcast
+  int n1, n2;
+  long long sx[3], sm[3], sl[3];
+};
+
+template <bool EPS>
+__global__ void gauss_logdensity_fwd_kernel(const float* __restrict__ x, const float* __restrict__ mu,
+                                            const float* __restrict__ lv, float* __restrict__ out, Bc3 b, size_t n) {
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) {
+    const long long i2 = (long long)(e % b.n2), r = (long long)(e / b.n2), i1 = r % b.n1, i0 = r / b.n1;
+    const float d = x[i0 * b.sx[0] + i1 * b.sx[1] + i2 * b.sx[2]] - mu[i0 * b.sm[0] + i1 * b.sm[1] + i2 * b.sm[2]];
+    out[e] = fmaxf(logdens<EPS>(d, lv[i0 * b.sl[0] + i1 * b.sl[1] + i2 * b.sl[2]]), kFloor);
+  }
+}
+
+// elementwise gradients at the broadcast shape: dx (= -dmu) and dlogvar; zero where the -50 clamp is active;
+// EPS: derivative with respect to the variance taken at the clamped value and handed to exp(logvar) unchanged
+// (F.gaussian_nll_loss clamps a detached copy: straight-through), ops.py:17-21
+template <bool EPS>
+__global__ void gauss_logdensity_bwd_kernel(const float* __restrict__ g, const float* __restrict__ x,
+                                            const float* __restrict__ mu, const float* __restrict__ lv,
+                                            float* __restrict__ dx, float* __restrict__ dlv, Bc3 b, size_t n) {
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) {
+    const long long i2 = (long long)(e % b.n2), r = (long long)(e / b.n2), i1 = r % b.n1, i0 = r / b.n1;
+    const float d = x[i0 * b.sx[0] + i1 * b.sx[1] + i2 * b.sx[2]] - mu[i0 * b.sm[0] + i1 * b.sm[1] + i2 * b.sm[2]];
+    const float l = lv[i0 * b.sl[0] + i1 * b.sl[1] + i2 * b.sl[2]];
+    const float gg = g[e];
+    float gx = 0.f, gl = 0.f;
+    if (logdens<EPS>(d, l) >= kFloor) {
+      if (EPS) {
+        const float var = expf(l), ivh = 1.f / fmaxf(var, kVarEps), dv = d * ivh;
+        gx = -gg * dv;
+        gl = -gg * 0.5f * (ivh - dv * dv) * var;
+      } else {
+        const float iv = expf(-l);
+        gx = -gg * d * iv;
+        gl = -gg * 0.5f * (1.f - d * d * iv);
+      }
+    }
+    dx[e] = gx, dlv[e] = gl;
+  }
+}
+
+// ops.py:92-115 on a materialised lp[B][B][D]: block per row j.  S[j][i] = logW + sum_l lp, lse[j][l] are kept for
+// the backward; logqz_raw is log q(z_j) before the weighted sampler's constant.
+template <bool MWS>
+__global__ __launch_bounds__(256) void sampling_fwd_kernel(const float* __restrict__ lp, float* __restrict__ prodm,
+                                                           float* __restrict__ logqz, float* __restrict__ lse,
+                                                           float* __restrict__ sj, int B, int D, TcConst c) {
+  __shared__ float red[4];
+  const int j = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const float* row = lp + (size_t)j * B * D;
+  for (int i = wid; i < B; i += 4) {
+    float s = 0.f;
+    for (int l = lane; l < D; l += 64) s += row[(size_t)i * D + l];
+    s = wave_sum(s);
+    if (lane == 0) sj[(size_t)j * B + i] = s + (MWS ? 0.f : log_iw(c, j, i));
+  }
+  float prod_acc = 0.f;
+  for (int l = tid; l < D; l += 256) {
+    float m = -INFINITY;
+    for (int i = 0; i < B; ++i) m = fmaxf(m, row[(size_t)i * D + l] + (MWS ? 0.f : log_iw(c, j, i)));
+    float se = 0.f;
+    for (int i = 0; i < B; ++i) se += expf(row[(size_t)i * D + l] + (MWS ? 0.f : log_iw(c, j, i)) - m);
+    const float r = m + logf(se);
+    lse[(size_t)j * D + l] = r;
+    prod_acc += MWS ? r - c.log_bn : r;
+  }
+  __syncthreads();   // the S row written above is read by the whole block
+  float mx = -INFINITY;
+  for (int i = tid; i < B; i += 256) mx = fmaxf(mx, sj[(size_t)j * B + i]);
+  mx = wave_max(mx);
+  if (lane == 0) red[wid] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  __syncthreads();
+  float se = 0.f;
+  for (int i = tid; i < B; i += 256) se += expf(sj[(size_t)j * B + i] - mx);
+  se = block_sum(se, red);
+  const float pm = block_sum(prod_acc, red);
+  if (tid == 0) {
+    logqz[j] = mx + logf(se) - (MWS ? c.log_bn : 0.f);
+    prodm[j] = pm;
+  }
+}
+
+// d lp[j][i][l] = g_prodm[j] * softmax_i(logW + lp)[j][i][l] + g_logqz[j] * softmax_i(S)[j][i]
+template <bool MWS>
+__global__ __launch_bounds__(256) void sampling_bwd_kernel(const float* __restrict__ gp, const float* __restrict__ gq,
+                                                           const float* __restrict__ lp, const float* __restrict__ lse,
+                                                           const float* __restrict__ sj, const float* __restrict__ logqz,
+                                                           float* __restrict__ dlp, int B, int D, TcConst c) {
+  const int j = blockIdx.x, i = blockIdx.y;
+  const float liw = MWS ? 0.f : log_iw(c, j, i);
+  const float lq = logqz[j] + (MWS ? c.log_bn : 0.f);
+  const float wq = gq[j] * expf(sj[(size_t)j * B + i] - lq), g1 = gp[j];
+  const size_t base = ((size_t)j * B + i) * D;
+  for (int l = threadIdx.x; l < D; l += 256) dlp[base + l] = g1 * expf(lp[base + l] + liw - lse[(size_t)j * D + l]) + wq;
+}
+
+// ops.py:118-122 for a 2-D x[m][n] (m == n, or m == 1): diag[k] = x[k][k]; off[a][i][k] = x[i][k] - (i == k) * x[a][i]
+// (torch.diag_embed puts the LAST dimension of x on the diagonal of a new trailing pair and x broadcasts against it)
+__global__ void on_off_diag_kernel(const float* __restrict__ x, float* __restrict__ diag, float* __restrict__ off, int m,
+                                   int n) {
+  const size_t total = (size_t)m * n * n;
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+    const int k = (int)(e % n), i = (int)((e / n) % n), a = (int)(e / ((size_t)n * n));
+    const float xv = x[(size_t)(m == 1 ? 0 : i) * n + k];
+    off[e] = xv - (i == k ? x[(size_t)a * n + i] : 0.f);
+    if (e < (size_t)(m < n ? m : n)) diag[e] = x[e * n + e];
+  }
+}
+
 static int make_const(const char* name, int Bt, int64_t N, TcConst* c) {
   if (Bt < 2) return fail("%s: batch size must be >= 2 (M = B-1 divides the weights; ops.py:43-45)", name);
   if (N <= 0) return fail("%s: dataset_size must be positive", name);
@@ -446,6 +562,82 @@ int itcv_tc_bwd(const float* g, const float* z, const float* mu_all, const float
   hipLaunchKernelGGL(tc_bwd_cols_kernel, dim3(Bt, lch), dim3(256), 0, st, g, z, mu_all, logvar, lse, wq, dmu_all, Bl, Bt,
                      row_offset, D, c);
   ITCV_CHECK_LAUNCH("itcv_tc_bwd(cols)");
+  return 0;
+}
+
+static Bc3 make_bc3(const int64_t* dims, const int64_t* sx, const int64_t* sm, const int64_t* sl) {
+  Bc3 b;
+  b.n1 = (int)dims[1], b.n2 = (int)dims[2];
+  for (int k = 0; k < 3; ++k) b.sx[k] = sx[k], b.sm[k] = sm[k], b.sl[k] = sl[k];
+  return b;
+}
+
+int itcv_gauss_logdensity_fwd(const float* x, const float* mu, const float* logvar, float* out, const int64_t* dims,
+                              const int64_t* sx, const int64_t* sm, const int64_t* sl, int eps_density, void* stream) {
+  ITCV_REQUIRE(x && mu && logvar && out && dims && sx && sm && sl, "itcv_gauss_logdensity_fwd");
+  ITCV_REQUIRE(dims[0] > 0 && dims[1] > 0 && dims[2] > 0 && dims[1] < (1ll << 31) && dims[2] < (1ll << 31),
+               "itcv_gauss_logdensity_fwd(shape)");
+  const size_t n = (size_t)dims[0] * dims[1] * dims[2];
+  const Bc3 b = make_bc3(dims, sx, sm, sl);
+  if (eps_density)
+    hipLaunchKernelGGL(gauss_logdensity_fwd_kernel<true>, dim3(ew_grid(n)), dim3(256), 0, S(stream), x, mu, logvar, out, b, n);
+  else
+    hipLaunchKernelGGL(gauss_logdensity_fwd_kernel<false>, dim3(ew_grid(n)), dim3(256), 0, S(stream), x, mu, logvar, out, b, n);
+  ITCV_CHECK_LAUNCH("itcv_gauss_logdensity_fwd");
+  return 0;
+}
+
+int itcv_gauss_logdensity_bwd(const float* g, const float* x, const float* mu, const float* logvar, float* dx,
+                              float* dlogvar, const int64_t* dims, const int64_t* sx, const int64_t* sm,
+                              const int64_t* sl, int eps_density, void* stream) {
+  ITCV_REQUIRE(g && x && mu && logvar && dx && dlogvar && dims && sx && sm && sl, "itcv_gauss_logdensity_bwd");
+  ITCV_REQUIRE(dims[0] > 0 && dims[1] > 0 && dims[2] > 0 && dims[1] < (1ll << 31) && dims[2] < (1ll << 31),
+               "itcv_gauss_logdensity_bwd(shape)");
+  const size_t n = (size_t)dims[0] * dims[1] * dims[2];
+  const Bc3 b = make_bc3(dims, sx, sm, sl);
+  if (eps_density)
+    hipLaunchKernelGGL(gauss_logdensity_bwd_kernel<true>, dim3(ew_grid(n)), dim3(256), 0, S(stream), g, x, mu, logvar, dx,
+                       dlogvar, b, n);
+  else
+    hipLaunchKernelGGL(gauss_logdensity_bwd_kernel<false>, dim3(ew_grid(n)), dim3(256), 0, S(stream), g, x, mu, logvar, dx,
+                       dlogvar, b, n);
+  ITCV_CHECK_LAUNCH("itcv_gauss_logdensity_bwd");
+  return 0;
+}
+
+int itcv_sampling_fwd(const float* lp, float* prodm, float* logqz, float* lse, float* sjoint, int B, int D,
+                      int64_t dataset_size, int weighted, void* stream) {
+  ITCV_REQUIRE(lp && prodm && logqz && lse && sjoint && B > 0 && D > 0, "itcv_sampling_fwd");
+  TcConst c;
+  if (int e = make_const("itcv_sampling_fwd", B, dataset_size, &c)) return e;
+  if (weighted)
+    hipLaunchKernelGGL(sampling_fwd_kernel<true>, dim3(B), dim3(256), 0, S(stream), lp, prodm, logqz, lse, sjoint, B, D, c);
+  else
+    hipLaunchKernelGGL(sampling_fwd_kernel<false>, dim3(B), dim3(256), 0, S(stream), lp, prodm, logqz, lse, sjoint, B, D, c);
+  ITCV_CHECK_LAUNCH("itcv_sampling_fwd");
+  return 0;
+}
+
+int itcv_sampling_bwd(const float* g_prodm, const float* g_logqz, const float* lp, const float* lse, const float* sjoint,
+                      const float* logqz, float* dlp, int B, int D, int64_t dataset_size, int weighted, void* stream) {
+  ITCV_REQUIRE(g_prodm && g_logqz && lp && lse && sjoint && logqz && dlp && B > 0 && D > 0, "itcv_sampling_bwd");
+  ITCV_REQUIRE(B <= 65535, "itcv_sampling_bwd(batch)");
+  TcConst c;
+  if (int e = make_const("itcv_sampling_bwd", B, dataset_size, &c)) return e;
+  if (weighted)
+    hipLaunchKernelGGL(sampling_bwd_kernel<true>, dim3(B, B), dim3(256), 0, S(stream), g_prodm, g_logqz, lp, lse, sjoint,
+                       logqz, dlp, B, D, c);
+  else
+    hipLaunchKernelGGL(sampling_bwd_kernel<false>, dim3(B, B), dim3(256), 0, S(stream), g_prodm, g_logqz, lp, lse, sjoint,
+                       logqz, dlp, B, D, c);
+  ITCV_CHECK_LAUNCH("itcv_sampling_bwd");
+  return 0;
+}
+
+int itcv_on_off_diag(const float* x, float* diag, float* off, int m, int n, void* stream) {
+  ITCV_REQUIRE(x && diag && off && m > 0 && n > 0 && (m == n || m == 1), "itcv_on_off_diag");
+  hipLaunchKernelGGL(on_off_diag_kernel, dim3(ew_grid((size_t)m * n * n)), dim3(256), 0, S(stream), x, diag, off, m, n);
+  ITCV_CHECK_LAUNCH("itcv_on_off_diag");
   return 0;
 }
 

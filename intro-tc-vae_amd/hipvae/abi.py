@@ -28,7 +28,6 @@ p, i32, i64, sz, f32, f64 = (ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctyp
 SIGNATURES = {
     "itcv_abi_version": (i32, []),
     "itcv_last_error": (ctypes.c_char_p, []),
-    "itcv_on_abort_print": (i32, [ctypes.c_char_p]),
     "itcv_profile_begin": (i32, []),
     "itcv_profile_end": (i32, []),
     "itcv_profile_get": (i32, [i32, p, p, p]),
@@ -110,6 +109,11 @@ SIGNATURES = {
     "itcv_tc_bwd_workspace": (sz, [i32, i32]),
     "itcv_tc_bwd": (i32, [p, p, p, p, p, p, p, p, p, p, i32, i32, i32, i32, i64, i32, p, sz, p]),
     "itcv_diag_logdensity_rows": (i32, [p, p, p, p, p, i32, i32, p]),
+    "itcv_gauss_logdensity_fwd": (i32, [p, p, p, p, p, p, p, p, i32, p]),
+    "itcv_gauss_logdensity_bwd": (i32, [p, p, p, p, p, p, p, p, p, p, i32, p]),
+    "itcv_sampling_fwd": (i32, [p, p, p, p, p, i32, i32, i64, i32, p]),
+    "itcv_sampling_bwd": (i32, [p, p, p, p, p, p, p, i32, i32, i64, i32, p]),
+    "itcv_on_off_diag": (i32, [p, p, p, i32, i32, p]),
     "itcv_recon_workspace": (sz, [i32, sz]),
     "itcv_recon_rows_fwd": (i32, [p, p, p, i32, sz, i32, p, sz, p]),
     "itcv_recon_rows_bwd": (i32, [p, p, p, p, i32, sz, i32, p]),

@@ -129,6 +129,27 @@ def graph_capturable():
             and os.environ.get("ITCV_DDP_GRAPH", "0") == "1")
 
 
+def drain_pending_collectives():
+    """Block until RCCL's watchdog thread has retired every collective this process has issued so far (call after a
+    device synchronize).  Needed in front of a hipGraph capture of the data-parallel step: see solvers/vae.py.
+    ``ProcessGroup._wait_for_pending_works`` = c10d::ProcessGroupNCCL::waitForPendingWorks, which returns once the
+    watchdog's work list is empty; gloo groups have no watchdog and return at once."""
+    c = get()
+    if c is None:
+        return
+    groups = {id(c.group): c.group}
+    try:
+        import models
+        g = models.HipBatchNorm2d.sync_group
+        if g is not None:
+            groups[id(g)] = g
+    except ImportError:
+        pass
+    for g in groups.values():
+        if dist.get_backend(g) == "nccl":
+            g._wait_for_pending_works()
+
+
 def mean_scalars_(vec):
     """Average a small vector of per-rank loss scalars so every rank reports the global value."""
     c = get()

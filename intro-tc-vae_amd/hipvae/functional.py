@@ -1004,6 +1004,93 @@ class TcRowsFn(Function):
         return dz, dmu, dlv, None, None
 
 
+def _bc3(x, mu, logvar):
+    """The three operands as (same-storage) views broadcast to one shape of at most three dimensions, with their element
+    strides (0 on broadcast dimensions) as ctypes arrays."""
+    import ctypes
+    x, mu, logvar = (t if t.dtype == F32 else t.float() for t in (x, mu, logvar))
+    xb, mb, lb = torch.broadcast_tensors(x, mu, logvar)
+    shape = tuple(xb.shape)
+    if len(shape) > 3:    # collapse the leading dimensions (needs dense operands there)
+        xb, mb, lb = (t.contiguous().reshape(-1, *shape[-2:]) for t in (xb, mb, lb))
+    while xb.dim() < 3:
+        xb, mb, lb = xb.unsqueeze(0), mb.unsqueeze(0), lb.unsqueeze(0)
+    arr = lambda v: (ctypes.c_int64 * 3)(*v)
+    return shape, (xb, mb, lb), arr(xb.shape), arr(xb.stride()), arr(mb.stride()), arr(lb.stride())
+
+
+class GaussLogDensityFn(Function):
+    """ops.py:15-21 (``eps_density``) / ops.py:24-29 on broadcastable operands, materialised."""
+
+    @staticmethod
+    def forward(ctx, x, mu, logvar, eps_density):
+        shape, views, dims, sx, sm, sl = _bc3(x, mu, logvar)
+        out = torch.empty(tuple(views[0].shape), dtype=F32, device=views[0].device)
+        for v in views:
+            if not v.is_cuda:
+                raise abi.HipExtensionError("HIP kernels need device tensors (got a CPU tensor); there is no CPU path")
+        call("itcv_gauss_logdensity_fwd", views[0].data_ptr(), views[1].data_ptr(), views[2].data_ptr(), ptr(out), dims, sx,
+             sm, sl, int(eps_density), stream())
+        ctx.save_for_backward(x, mu, logvar)
+        ctx.eps_density = int(eps_density)
+        return out.reshape(shape)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        x, mu, logvar = ctx.saved_tensors
+        shape, views, dims, sx, sm, sl = _bc3(x, mu, logvar)
+        g = _f32c(g).reshape(tuple(views[0].shape))
+        dx, dlv = torch.empty_like(g), torch.empty_like(g)
+        call("itcv_gauss_logdensity_bwd", ptr(g), views[0].data_ptr(), views[1].data_ptr(), views[2].data_ptr(), ptr(dx),
+             ptr(dlv), dims, sx, sm, sl, ctx.eps_density, stream())
+        dx, dlv = dx.reshape(shape), dlv.reshape(shape)
+        # un-broadcast (torch reduction: plumbing of this off-path helper, not step arithmetic)
+        return (dx.sum_to_size(x.shape) if ctx.needs_input_grad[0] else None,
+                (-dx).sum_to_size(mu.shape) if ctx.needs_input_grad[1] else None,
+                dlv.sum_to_size(logvar.shape) if ctx.needs_input_grad[2] else None, None)
+
+
+class SamplingFn(Function):
+    """ops.py:104-115 / ops.py:92-101 on a materialised [B,B,D] log-density tensor -> (prodm[B], logqz[B])."""
+
+    @staticmethod
+    def forward(ctx, lp, dataset_size, weighted):
+        lp = _f32c(lp)
+        B, B2, D = lp.shape
+        if B != B2:
+            raise abi.HipExtensionError(f"sampling: log_qz_prob must be [B,B,D] (got {tuple(lp.shape)})")
+        dev = lp.device
+        prodm, logqz = torch.empty((B,), dtype=F32, device=dev), torch.empty((B,), dtype=F32, device=dev)
+        lse, sj = torch.empty((B, D), dtype=F32, device=dev), torch.empty((B, B), dtype=F32, device=dev)
+        call("itcv_sampling_fwd", ptr(lp), ptr(prodm), ptr(logqz), ptr(lse), ptr(sj), B, D, int(dataset_size), int(weighted),
+             stream())
+        ctx.save_for_backward(lp, lse, sj, logqz)
+        ctx.cfg = (B, D, int(dataset_size), int(weighted))
+        return prodm, logqz
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gp, gq):
+        lp, lse, sj, logqz = ctx.saved_tensors
+        B, D, n, weighted = ctx.cfg
+        dlp = torch.empty_like(lp)
+        call("itcv_sampling_bwd", ptr(_f32c(gp)), ptr(_f32c(gq)), ptr(lp), ptr(lse), ptr(sj), ptr(logqz), ptr(dlp), B, D, n,
+             weighted, stream())
+        return dlp, None, None
+
+
+def on_off_diag(x):
+    x = _f32c(x)
+    if x.dim() != 2 or not (x.shape[0] == x.shape[1] or x.shape[0] == 1):
+        raise abi.HipExtensionError(f"on_off_diag: a [n,n] or [1,n] tensor is expected (got {tuple(x.shape)})")
+    m, n = x.shape
+    diag = torch.empty((min(m, n),), dtype=F32, device=x.device)
+    off = torch.empty((m, n, n), dtype=F32, device=x.device)
+    call("itcv_on_off_diag", ptr(x), ptr(diag), ptr(off), m, n, stream())
+    return diag, off
+
+
 def diag_logdensity_rows(z, mu, logvar):
     z, mu, logvar = _f32c(z), _f32c(mu), _f32c(logvar)
     B, D = z.shape

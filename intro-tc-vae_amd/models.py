@@ -53,6 +53,31 @@ def bn_groups(groups):
         _BN_GROUPS[0] = prev
 
 
+# Forward hooks.  The reference's anomaly detection registers an `isnan` hook on EVERY submodule (train.py:119-138).  On the
+# fused schedule leaf modules are bypassed (LeakyReLU / pooling / upsampling run inside the BatchNorm and conv kernels)
+# and, in the split-bf16 modes, an intermediate fp32 tensor may never be written (its consumers read planes).  So a
+# network with any forward (pre-)hook registered below it runs the reference's own module-by-module sequence instead
+# (`_HOOKED`): every submodule is called, in the reference's order, and every output it hands to a hook is a fully
+# written fp32 tensor.  Same kernels, a few more launches.
+_HOOKED = [False]
+
+
+def _has_hooks(mod):
+    g = nn.modules.module
+    if g._global_forward_hooks or g._global_forward_pre_hooks:
+        return True
+    return any(m._forward_hooks or m._forward_pre_hooks for m in mod.modules())
+
+
+@contextlib.contextmanager
+def _hooked_scope(flag):
+    prev, _HOOKED[0] = _HOOKED[0], bool(flag)
+    try:
+        yield
+    finally:
+        _HOOKED[0] = prev
+
+
 def _add(a, b):
     return a + b if _CPU_WARMUP[0] else HF.AddFn.apply(a, b)
 
@@ -156,6 +181,10 @@ class ConvolutionalBlock(nn.Module):
 
     def forward(self, x, pool=False, up2=False, consumer=None, consumer_up2=False):
         """``consumer``: the conv module that reads this block's output (its planes are emitted by bn2)."""
+        if _HOOKED[0]:      # models.py:49-54, module by module
+            y = self.relu1(self.bn1(self.conv1(x, up2=up2)))
+            y = self.relu2(self.bn2(self.conv2(y)))
+            return _avgpool2(y) if pool else y
         B, H, W = x.size(0), x.size(2) * (2 if up2 else 1), x.size(3) * (2 if up2 else 1)
         y = self.bn1(self.conv1(x, up2=up2), slope=LRELU_SLOPE, out_mode=HF.conv_input_mode(self.conv2, B, H, W),
                      grad_mode=HF.conv_grad_mode(self.conv1, B, H, W, x.requires_grad))
@@ -184,6 +213,13 @@ class ResidualBlock(nn.Module):
         self.relu2 = HipLeakyReLU(LRELU_SLOPE, inplace=True)
 
     def forward(self, x, pool=False, up2=False, consumer=None, consumer_up2=False):
+        if _HOOKED[0]:      # models.py:104-115, module by module
+            if up2:
+                x = _upsample2(x)
+            identity = self.conv_expand(x) if self.conv_expand is not None else x
+            y = self.relu1(self.bn1(self.conv1(x)))
+            y = self.relu2(_add(self.bn2(self.conv2(y)), identity))
+            return _avgpool2(y) if pool else y
         if self.conv_expand is not None:
             skip = self.conv_expand(x, up2=up2)
         else:
@@ -210,6 +246,8 @@ class Conv2dBatchNorm(nn.Module):
         self.relu = HipLeakyReLU(LRELU_SLOPE, inplace=True)
 
     def forward(self, x, up2=False):
+        if _HOOKED[0]:      # models.py:134-138
+            return self.relu(self.batch_norm(self.conv(x, up2=up2)))
         return self.batch_norm(self.conv(x, up2=up2), slope=LRELU_SLOPE)
 
 
@@ -305,7 +343,11 @@ class Encoder(nn.Module):
                 m.num_batches_tracked.fill_(1)
 
     def forward(self, x):
-        if self.fused:
+        hooked = _has_hooks(self)
+        if hooked:
+            with _hooked_scope(True):
+                y = self.main(x)
+        elif self.fused:
             blocks = [getattr(self.main, name) for name, _ in self._stages]
             res_block = not isinstance(blocks[0], ConvolutionalBlock)    # skip paths / branches read the fp32 tensor
             first = getattr(blocks[0], "conv1", None)
@@ -356,7 +398,10 @@ class Decoder(nn.Module):
     def forward(self, z):
         z = z.reshape(z.size(0), -1)
         y = self.fc(z).view(z.size(0), *self.conv_input_size)
-        if self.fused:
+        if _has_hooks(self):
+            with _hooked_scope(True):
+                y = self.main(y)
+        elif self.fused:
             blocks = [getattr(self.main, name) for name in self._stages]
             for k, blk in enumerate(blocks):   # the upsample before block k folds into its conv
                 nxt = getattr(blocks[k + 1], "conv1", None) if k + 1 < len(blocks) else self.main.predict

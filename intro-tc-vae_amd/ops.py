@@ -3,9 +3,11 @@
 Same names, argument order and error behaviour as /root/reference/ops.py (cited per
 function); the arithmetic runs in libitcv_hip.so (hipvae.functional).  Differences that a
 caller can observe are limited to:
-  * the [B,B,D] pairwise tensor is never materialised, so the reference's helpers that take
-    that tensor as an argument (``minibatch_*_sampling``) are offered in fused form
-    (``tc_components``) instead;
+  * ``total_correlation`` never materialises the [B,B,D] pairwise tensor (fused kernels; ``tc_components`` /
+    ``tc_decomposition`` expose the fused estimator); the reference's building blocks that produce or take that
+    tensor -- ``gaussian_log_density_torch``, ``gaussian_log_density``, ``minibatch_stratified_sampling``,
+    ``minibatch_weighted_sampling``, ``on_off_diag`` -- exist under their own names in materialising form, so code
+    that imports them (solvers/tc.py:5-11) keeps working;
   * the N(0,1) draws of ``reparameterize`` come from ``noise`` (device generator by default;
     ``set_noise_mode("host")`` reproduces the reference's CPU stream, ``noise_queue`` injects
     recorded draws for parity tests).
@@ -91,6 +93,36 @@ def reconstruction_loss(x, recon_x, loss_type="mse", reduction="sum"):
     if reduction == "mean":
         return rows.mean()
     return rows
+
+
+def gaussian_log_density_torch(x, mu, logvar):
+    """ops.py:15-21: -gaussian_nll_loss(x, mu, exp(logvar), eps=1e-4, full=True) clamped at -50, elementwise over the
+    broadcast of the three operands; the variance floor passes the gradient straight through (as F.gaussian_nll_loss
+    does), the -50 clamp blocks it."""
+    return HF.GaussLogDensityFn.apply(x, mu, logvar, True)
+
+
+def gaussian_log_density(x, mu, logvar):
+    """ops.py:24-29: -0.5 * ((x-mu)^2 exp(-logvar) + logvar + log 2 pi) clamped at -50."""
+    return HF.GaussLogDensityFn.apply(x, mu, logvar, False)
+
+
+def minibatch_weighted_sampling(log_qz_prob, batch_size, dataset_size):
+    """ops.py:92-101 on a materialised [B,B,D] tensor -> (logqz_prodmarginals [B], log_qz [B])."""
+    assert log_qz_prob.size(0) == batch_size
+    return HF.SamplingFn.apply(log_qz_prob, int(dataset_size), True)
+
+
+def minibatch_stratified_sampling(log_qz_prob, batch_size, dataset_size):
+    """ops.py:104-115 on a materialised [B,B,D] tensor -> (logqz_prodmarginals [B], log_qz [B])."""
+    assert log_qz_prob.size(0) == batch_size
+    return HF.SamplingFn.apply(log_qz_prob, int(dataset_size), False)
+
+
+def on_off_diag(x):
+    """ops.py:118-122 (never called by the reference): (torch.diagonal(x), x - torch.diag_embed(x)) for a 2-D x.
+    No gradient is recorded."""
+    return HF.on_off_diag(x)
 
 
 def total_correlation(z, mu, logvar, dataset_size, reduce="mean", mu_all=None, row_offset=0):

@@ -176,19 +176,18 @@ class VAESolver:
             torch.cuda.synchronize()
             ent["graph"] = torch.cuda.CUDAGraph()
             # thread-local capture mode: the input pipeline's staging thread (hipvae.loader) may allocate pinned memory or
-            # issue copies on its own stream while this thread captures.  Data-parallel capture keeps the default (global)
-            # mode and first lets RCCL's watchdog thread retire the collectives of the eager steps: the watchdog polls the
-            # end events of its outstanding work items every 100 ms, and a poll that lands inside the capture -- those
-            # events live on the communicator's stream, which joins the capture -- aborts the process ("operation not
-            # permitted on an event last recorded in a capturing stream" / "... when stream is capturing"; seen as a
-            # one-in-several race before this drain).  Collectives issued during the capture are not handed to the
-            # watchdog (ProcessGroupNCCL skips work enqueued from a capturing stream).
-            mode = "thread_local" if ddp.get() is None else "global"
-            if ddp.get() is not None:
-                import os
-                import time
-                # everything is complete (synchronize above): > 3 watchdog periods (ITCV_DDP_DRAIN overrides; diagnostic)
-                time.sleep(float(os.environ.get("ITCV_DDP_DRAIN", "0.35")))
+            # issue copies on its own stream while this thread captures, and RCCL's watchdog thread may query events.
+            # Data-parallel capture additionally needs the watchdog's work list EMPTY before the capture begins: the
+            # watchdog polls the end events of the eager steps' collectives, those events live on the communicator's
+            # stream, that stream joins the capture, and HIP refuses a query on such an event ("operation not permitted
+            # on an event last recorded in a capturing stream" / "... when stream is capturing" -> abort()).
+            # ddp.drain_pending_collectives() blocks on exactly that condition (ProcessGroupNCCL::waitForPendingWorks: the
+            # watchdog has retired every enqueued Work); the device is idle (synchronize above) so it terminates, and
+            # collectives issued DURING a capture are never handed to the watchdog (c10d skips the enqueue when the
+            # current stream is capturing) -- nothing is left for it to poll until the first eager collective after the
+            # capture.  No timing assumption.
+            ddp.drain_pending_collectives()
+            mode = "thread_local"
             with torch.cuda.graph(ent["graph"], capture_error_mode=mode):
                 ent["out"] = self._device_step(ent["inp"])
             graphs[key] = ent

@@ -147,24 +147,13 @@ def test_conv_expand_identity_quirk():
     assert "encoder.main.res_in_4.conv_expand.weight" not in r.state_dict()
 
 
-def test_abort_hook_prints_the_prepared_line():
-    """bench.py's last-words hook (itcv_on_abort_print): armed, abort() from any thread writes the prepared line to stdout
-    and the process leaves with status 0; disarmed, abort() is the default SIGABRT again; the pack-descriptor queries
-    answer without a GPU."""
+def test_pack_descriptor_queries_answer_without_a_gpu():
+    """The pack-descriptor queries are pure host arithmetic; the product library carries no signal handlers (the SIGABRT
+    hook of round 2 is gone: bench.py isolates its optional N>1 leg in a child process instead)."""
     import subprocess
-    import sys
-    pre = ("import sys, os, ctypes\nsys.path.insert(0, %r)\nfrom hipvae import abi\n"
-           % os.path.join(ROOT, "intro-tc-vae_amd"))
-    armed = subprocess.run([sys.executable, "-c", pre + "abi.lib.itcv_on_abort_print(b'{\"x\": 1}')\n"
-                            "import threading\nt = threading.Thread(target=os.abort)\nt.start()\nt.join()\n"],
-                           capture_output=True, text=True, timeout=120)
-    assert armed.returncode == 0 and armed.stdout == '{"x": 1}\n'
-    quiet = subprocess.run([sys.executable, "-c", pre + "abi.lib.itcv_on_abort_print(b'')\nos.abort()\n"],
-                           capture_output=True, text=True, timeout=120)
-    assert quiet.returncode == 0 and quiet.stdout == ""
-    off = subprocess.run([sys.executable, "-c", pre + "abi.lib.itcv_on_abort_print(b'x')\n"
-                          "abi.lib.itcv_on_abort_print(None)\nos.abort()\n"], capture_output=True, text=True, timeout=120)
-    assert off.returncode == -6 and off.stdout == ""
+    nm = subprocess.run(["nm", "-D", "--defined-only", os.path.join(ROOT, "intro-tc-vae_amd", "lib", "libitcv_hip.so")],
+                        capture_output=True, text=True).stdout
+    assert "itcv_on_abort_print" not in nm and " signal" not in nm
     from hipvae import abi
     assert abi.lib.itcv_pack_desc_bytes() == 56
     buf = (ctypes.c_uint8 * 56)()

@@ -77,6 +77,88 @@ def test_model_forward_backward_golden(arch, fused):
     assert rel_err(mu_e, g["eval_mu"]) < 1e-4 and rel_err(rec_e, g["eval_rec"]) < 1e-4
 
 
+@pytest.mark.parametrize("arch", ["conv", "res", "inception"])
+@pytest.mark.parametrize("math", ["fp32", "bf16x3"])
+def test_forward_hooks_on_every_submodule(arch, math):
+    """/root/reference/train.py:119-138 (anomaly detection): an `isnan` forward hook on every submodule.  With hooks
+    registered the networks run the reference's module-by-module sequence: EVERY named submodule's hook fires, every
+    output a hook sees is a completely written fp32 tensor (no NaN even when planes-only tensors are poisoned with NaN:
+    HF._POISON), and mu / logvar / reconstruction equal the fused schedule's (golden values, 1e-4)."""
+    import ops
+    from hipvae import functional as HF
+    g = np.load(os.path.join(GOLDEN, f"model_{arch}.npz"))
+    model = build(arch, load_state(g, "init:"))
+    x = T(g["x"]).to(dev())
+    fired, bad = set(), []
+
+    def make(name):
+        def hook(mod, _, output):
+            outs = output if isinstance(output, tuple) else [output]
+            fired.add(name)
+            for o in outs:
+                if torch.isnan(o).any():
+                    bad.append(name)
+        return hook
+
+    handles = [m.register_forward_hook(make(n)) for n, m in model.named_modules()]
+    HF.set_conv_math(math)
+    prev, HF._POISON[0] = HF._POISON[0], True
+    try:
+        with ops.noise_queue([T(g["eps"])]):
+            mu, logvar, z, rec = model(x)
+    finally:
+        HF._POISON[0] = prev
+        HF.set_conv_math("fp32")
+    tol = 1e-4 if math == "fp32" else 2e-3
+    assert rel_err(mu, g["mu"]) < tol and rel_err(logvar, g["logvar"]) < tol and rel_err(rec, g["rec"]) < tol
+    assert not bad, bad
+    # conv_expand of the plain conv block exists for the state dict only and is never called (models.py:49-54)
+    expected = {n for n, m in model.named_modules() if not (arch == "conv" and n.endswith("conv_expand"))}
+    assert fired == expected, sorted(expected - fired)
+    (rec.sum() + mu.sum()).backward()           # the module-by-module graph is differentiable end to end
+    assert all(p.grad is not None for n, p in model.named_parameters() if "conv_expand" not in n)
+    for h in handles:
+        h.remove()
+    with ops.noise_queue([T(g["eps"])]):          # hooks gone: back on the fused schedule, same values
+        mu2, _, _, rec2 = model(x)
+    assert rel_err(mu2, g["mu"]) < 1e-4 and rel_err(rec2, g["rec"]) < 1e-4
+
+
+def test_forward_hooks_at_planes_widths():
+    """Channel widths that reach the planes kernels (bf16x3): on the fused schedule 8 of 13 conv inputs exist as planes
+    only; with hooks registered (and those fp32 tensors poisoned) every hook still sees finite, written values and the
+    outputs equal the fused schedule's to rounding."""
+    import models
+    import ops
+    from hipvae import functional as HF
+    torch.manual_seed(3)
+    model = models.SoftIntroVAE(arch="conv", cdim=3, zdim=16, channels=(64, 64, 128), image_size=32).to(dev()).train()
+    x = torch.rand(8, 3, 32, 32, generator=torch.Generator().manual_seed(1)).to(dev())
+    eps = torch.randn(8, 16, generator=torch.Generator().manual_seed(2))
+    HF.set_conv_math("bf16x3")
+    prev, HF._POISON[0] = HF._POISON[0], True
+    try:
+        with ops.noise_queue([eps]):
+            mu0, _, _, rec0 = model(x)
+        bad, n = [], [0]
+
+        def hook(mod, _, output):
+            n[0] += 1
+            if torch.isnan(output[0] if isinstance(output, tuple) else output).any():
+                bad.append(type(mod).__name__)
+
+        handles = [m.register_forward_hook(hook) for m in model.modules()]
+        with ops.noise_queue([eps]):
+            mu1, _, _, rec1 = model(x)
+        for h in handles:
+            h.remove()
+    finally:
+        HF._POISON[0] = prev
+        HF.set_conv_math("fp32")
+    assert not bad and n[0] > 60
+    assert rel_err(mu1, mu0) < 1e-4 and rel_err(rec1, rec0) < 1e-4
+
+
 class _DS:
     def __init__(self, n):
         self.n = n

@@ -274,6 +274,66 @@ def test_latent_against_golden(HF, tag):
     assert rel_err(ll.grad, T("tcw_dlogvar")) < 1e-4
 
 
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
+def test_named_density_and_sampling_functions_against_golden(HF, tag):
+    """The reference's building blocks under their own names (ops.py:15-29, 92-123), composed the way the reference
+    composes them (ops.py:80-89, solvers/tc.py:104-121): the materialised [B,B,D] log density against the oracle's,
+    the two samplers / the total correlation / the full decomposition against the reference-generated vectors, and the
+    gradients of (beta-1) TC + KL built from the named pieces against the reference's autograd.  1e-4 relative."""
+    import ops
+    from oracle import latent_math as OM
+    G = np.load(os.path.join(GOLDEN, "ops.npz"))
+    B, D, N = (int(v) for v in G[f"{tag}_BDN"])
+    d = dev()
+    zc, muc, lvc = (torch.from_numpy(G[f"{tag}_{k}"]) for k in ("z", "mu", "logvar"))
+    z, mu, lv = zc.to(d), muc.to(d), lvc.to(d)
+    T = lambda k: torch.from_numpy(G[f"{tag}_{k}"])  # noqa: E731
+    lp = ops.gaussian_log_density_torch(z.unsqueeze(1), mu.unsqueeze(0), lv.unsqueeze(1))
+    assert lp.shape == (B, B, D)
+    ref_lp = OM.log_density_clamped_var(zc.unsqueeze(1), muc.unsqueeze(0), lvc.unsqueeze(1))
+    assert float((lp.cpu() - ref_lp).abs().max()) < 1e-4 * 50          # values span [-50, ~5]
+    assert abs(float((lp <= -50).float().mean()) - float(T("frac_clamp50")[0])) < 1e-3
+    pm, lq = ops.minibatch_stratified_sampling(lp, B, N)
+    assert rel_err(pm, T("mss_prodm")) < 1e-4 and rel_err(lq, T("mss_logqz")) < 1e-4
+    pm, lq = ops.minibatch_weighted_sampling(lp, B, N)
+    assert rel_err(pm, T("mws_prodm")) < 1e-4 and rel_err(lq, T("mws_logqz")) < 1e-4
+    # solvers/tc.py:104-121: plain density, variance of component i
+    logq_cx = ops.gaussian_log_density(z, mu, lv).sum(1)
+    logpz = ops.gaussian_log_density(z, torch.zeros_like(z), torch.zeros_like(z)).sum(1)
+    lp2 = ops.gaussian_log_density(z.unsqueeze(1), mu.unsqueeze(0), lv.unsqueeze(0))
+    pm2, lq2 = ops.minibatch_stratified_sampling(lp2, B, N)
+    assert rel_err(logq_cx, T("full_logq_cx")) < 1e-4 and rel_err(logpz, T("full_logpz")) < 1e-4
+    assert rel_err(pm2, T("full_prodm")) < 1e-4 and rel_err(lq2, T("full_logqz")) < 1e-4
+    assert rel_err(logq_cx - lq2, T("full_mi")) < 1e-4 and rel_err(pm2 - logpz, T("full_dwkl")) < 1e-4
+    # gradients through the named pieces == the reference's autograd through its own
+    for beta, bt in ((512.0, "512p0"), (0.5, "0p5")):
+        zz, mm, ll = (t.clone().requires_grad_(True) for t in (z, mu, lv))
+        lpg = ops.gaussian_log_density_torch(zz.unsqueeze(1), mm.unsqueeze(0), ll.unsqueeze(1))
+        a, b = ops.minibatch_stratified_sampling(lpg, B, N)
+        loss = (beta - 1.0) * (b - a).mean() + ops.kl_divergence(ll, mm, "mean")
+        loss.backward()
+        assert rel_err(loss, T(f"tckl_b{bt}")) < 1e-4
+        assert rel_err(zz.grad, T(f"tckl_b{bt}_dz")) < 1e-4
+        assert rel_err(mm.grad, T(f"tckl_b{bt}_dmu")) < 1e-4
+        assert rel_err(ll.grad, T(f"tckl_b{bt}_dlogvar")) < 1e-4
+    # the plain density's gradient and the weighted sampler's, against torch autograd on the oracle's restatement
+    zz, mm, ll = (t.clone().requires_grad_(True) for t in (z, mu, lv))
+    a, b = ops.minibatch_weighted_sampling(ops.gaussian_log_density(zz.unsqueeze(1), mm.unsqueeze(0), ll.unsqueeze(0)), B, N)
+    w = torch.linspace(-1.0, 2.0, B)
+    ((b - 0.5 * a) * w.to(d)).sum().backward()
+    zr, mr, lr = (t.clone().double().requires_grad_(True) for t in (zc, muc, lvc))
+    ar, br = OM.weighted(OM.log_density_plain(zr.unsqueeze(1), mr.unsqueeze(0), lr.unsqueeze(0)), N)
+    ((br - 0.5 * ar) * w.double()).sum().backward()
+    assert rel_err(zz.grad, zr.grad) < 1e-4 and rel_err(mm.grad, mr.grad) < 1e-4 and rel_err(ll.grad, lr.grad) < 1e-4
+    # ops.py:118-122
+    x = torch.randn(7, 7, generator=torch.Generator().manual_seed(3))
+    dg, off = ops.on_off_diag(x.to(d))
+    assert torch.equal(dg.cpu(), torch.diagonal(x)) and torch.equal(off.cpu(), x - torch.diag_embed(x))
+    x1 = x[:1].contiguous()
+    dg, off = ops.on_off_diag(x1.to(d))
+    assert torch.equal(dg.cpu(), torch.diagonal(x1)) and torch.equal(off.cpu(), x1 - torch.diag_embed(x1))
+
+
 def test_tc_c4_eight_shards_against_golden(HF):
     """BASELINE configs[3] (c4): global batch 512 as 8 data-parallel shards of 64 rows.  Every shard evaluates its
     rows with the all-gathered means (``mu_all``) and its global ``row_offset`` -- what each rank of the 8-GPU run
