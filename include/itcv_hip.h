@@ -30,6 +30,14 @@ extern "C" {
 /* ---- library ------------------------------------------------------------------------- */
 int itcv_abi_version(void);
 const char* itcv_last_error(void);
+/* Launch-shape options (process-wide; the library reads NO environment variable).  Every option and value is part of
+ * the test matrix: results are bit-identical for any band_persist_blocks, and equal to rounding for band_m16.
+ *   "band_m16"             1 (default): v_mfma_f32_16x16x32_bf16 in the band / 128-pixel planes kernels; 0: 32x32x16
+ *   "band_persist_blocks"  256 (default): blocks of the persistent band kernel (used when a launch has more tiles);
+ *                          0: one tile per block; range 0..1024
+ * itcv_set_option returns non-zero for an unknown name or a value out of range; itcv_get_option returns -1 for an unknown name. */
+int itcv_set_option(const char* name, int value);
+int itcv_get_option(const char* name);
 
 /* Optional per-launch timing of the GEMM-class kernels (bench.py's roofline leg): between _begin and
  * _end every conv entry point records a HIP event pair on its launch stream around its MAIN kernel

@@ -1,5 +1,5 @@
 // Library-level entry points of libitcv_hip.so (error reporting, ABI version).
-#include "common.h"
+#include "conv_shared.h"
 
 #include <vector>
 
@@ -33,10 +33,31 @@ ProfScope::~ProfScope() {
   g_prof_start = g_prof_stop = nullptr;
 }
 thread_local hipEvent_t g_prof_start = nullptr, g_prof_stop = nullptr;
+Options g_opt;
 }
 
 extern "C" {
 int itcv_abi_version(void) { return ITCV_ABI_VERSION; }
+
+int itcv_set_option(const char* name, int value) {
+  if (!name) return itcv::fail("%s: null option name", "itcv_set_option");
+  if (!strcmp(name, "band_m16")) {
+    if (value != 0 && value != 1) return itcv::fail("%s: band_m16 takes 0 or 1 (got %lld)", "itcv_set_option", value);
+    itcv::g_opt.band_m16 = value;
+    return 0;
+  }
+  if (!strcmp(name, "band_persist_blocks")) {
+    if (value < 0 || value > 1024) return itcv::fail("%s: band_persist_blocks takes 0..1024 (got %lld)", "itcv_set_option", value);
+    itcv::g_opt.band_persist_blocks = value;
+    return 0;
+  }
+  return itcv::fail("%s: unknown option", "itcv_set_option");
+}
+int itcv_get_option(const char* name) {
+  if (name && !strcmp(name, "band_m16")) return itcv::g_opt.band_m16;
+  if (name && !strcmp(name, "band_persist_blocks")) return itcv::g_opt.band_persist_blocks;
+  return -1;
+}
 const char* itcv_last_error(void) { return itcv::g_err; }
 
 int itcv_profile_begin(void) {

@@ -343,19 +343,20 @@ __global__ __launch_bounds__(768) void conv_fwd_bf16p2_kernel(ConvArgsP2 a) {
 // become free (and the weight ring simply wraps to the next tile's first taps), and the MFMA waves' result stores of
 // tile t drain while tile t+1 is multiplied.  Barrier structure, counted waits, K order and arithmetic are those of the
 // one-tile kernel (bit-identical results).
-// NMW = 4 (64-row tiles, 16x16x32 form; diagnostic, ITCV_BAND_W4=1): four MFMA waves of a 64x64 block each instead of
-// eight of 64x32 -- a third fewer LDS fragment reads per MFMA (16 per 48 instead of 12 per 24).  Measured SLOWER (64 -> 64
-// @ 64x64: 100.8 -> 110.4 us, same box): with one MFMA wave per SIMD nothing fills the barrier / LDS-latency bubbles.
+// (Four MFMA waves of a 64x64 block each instead of eight of 64x32 -- a third fewer LDS fragment reads per MFMA -- were
+// built and measured SLOWER, 64 -> 64 @ 64x64: 100.8 -> 110.4 us on one box: with one MFMA wave per SIMD nothing fills the
+// barrier / LDS-latency bubbles.  Removed.)
 // ROWS2 (128- and 256-wide images): the 128-pixel tile is 2 rows x 64 columns instead of (half of) one row -- the band is
 // 4 x 66 chunks per plane row instead of 3 x 130, a third less ingest per tile.
-template <int LOG2W, int BM, bool UP2, int BN, bool M16 = false, int NMW = 8, bool ROWS2 = false>
-__global__ __launch_bounds__(64 * (NMW + 4)) void conv_fwd_bf16p3_kernel(ConvArgsP2 a) {
+template <int LOG2W, int BM, bool UP2, int BN, bool M16 = false, bool ROWS2 = false>
+__global__ __launch_bounds__(768) void conv_fwd_bf16p3_kernel(ConvArgsP2 a) {
+  constexpr int NMW = 8;
   // BN = 256 pixels per tile for W <= 64 (whole rows); BN = 128 for 128- and 256-wide images: one row, or one half of a
   // row whose band then takes its halo columns from the neighbouring half instead of the zero padding
   constexpr int W = 1 << LOG2W, WB = ROWS2 ? 64 : (W < BN ? W : BN), LOG2WB = ROWS2 ? 6 : (LOG2W < 7 ? LOG2W : 7), WP = WB + 2, KC = 4, NS = 2;
   static_assert(WB == (1 << LOG2WB) && (BN == 256 || BN == 128) && (!ROWS2 || (BN == 128 && LOG2W >= 7)), "band width");
   constexpr int WM = BN == 256 ? BM / 64 : 2, WN = NMW / WM, WTN = BN / WN, TM = BM / (32 * WM), TN = WTN / 32;
-  static_assert(TM >= 1 && TN >= 1 && WTN == 32 * TN && (NMW == 8 || (NMW == 4 && M16)), "wave tiling");
+  static_assert(TM >= 1 && TN >= 1 && WTN == 32 * TN, "wave tiling");
   constexpr int ASZ = NS * KC * BM;
   constexpr int PA = NS * KC * BM / 64 / 4;
   constexpr int G = band_taps_per_stage(BM, BN, LOG2W), NSTG = (9 + G - 1) / G;
@@ -669,43 +670,17 @@ __global__ __launch_bounds__(64 * (NMW + 4)) void conv_fwd_bf16p3_kernel(ConvArg
   }
 }
 
-static int p2_bm64_mid() {   // ITCV_P2_BM64=0: keep the 128-pixel-tile kernel for the mid-sized layers (diagnostic)
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("ITCV_P2_BM64");
-    v = (e && e[0] == '0') ? 0 : 1;
-  }
-  return v;
-}
 FwdPlanP2 plan_fwd_p2(int B, int Ci, int H, int W, int Co, int KS, int ns) {
   FwdPlanP2 p;
   memset(&p, 0, sizeof(p));
   const int lw = log2_exact(W), lh = log2_exact(H);
-  // ITCV_BAND_W4PX=1 (diagnostic): the band form for 4-pixel-wide images (the 4x4 layers).  Built, verified and measured
-  // no faster than the 128-pixel planes kernel (512 -> 512 @ 4x4 x 128 images: 302 vs 312 TFLOP/s): those launches are
-  // bound by streaming 9.4 MB of weights per 128-pixel tile, not by the 9x activation re-reads the band form removes.
-  static int w4 = -1;
-  if (w4 < 0) {
-    const char* e = getenv("ITCV_BAND_W4PX");
-    w4 = (e && e[0] == '1') ? 1 : 0;
-  }
-  if (KS != 3 || ns != 2 || lw < (w4 ? 2 : 3) || lw > 8 || lh < 0 || Ci % 32 || Co < 33) return p;
-  // 128- and 256-wide images: 128-pixel tiles (two rows x 64 columns), persistent kernel only.  4-wide images (the 4x4
-  // layers): 128-pixel tiles = 8 images of 4 rows, each with its own 6x6 halo'd band segment -- the band form reads
-  // 2.25 chunks per pixel and group where the 128-pixel planes kernel fetches every tap separately (9)
-  p.bn = (lw > 6 || lw == 2) ? 128 : 256;
-  static int enabled = -1;
-  if (enabled < 0) {
-    const char* e = getenv("ITCV_BF16P2");
-    enabled = (e && e[0] == '0') ? 0 : 1;
-  }
-  if (!enabled) return p;
-  static int rows2 = -1;   // ITCV_BAND_ROWS2=0: one (half) row per 128-pixel tile of a wide image (diagnostic)
-  if (rows2 < 0) {
-    const char* e = getenv("ITCV_BAND_ROWS2");
-    rows2 = (e && e[0] == '0') ? 0 : 1;
-  }
-  p.rows2 = (lw > 6 && H >= 2 && rows2) ? 1 : 0;
+  // (The band form for 4-pixel-wide images -- the 4x4 layers -- was built, verified and measured no faster than the
+  // 128-pixel planes kernel, 512 -> 512 @ 4x4 x 128 images: 302 vs 312 TFLOP/s: those launches are bound by streaming
+  // 9.4 MB of weights per 128-pixel tile, not by the 9x activation re-reads the band form removes.  Removed.)
+  if (KS != 3 || ns != 2 || lw < 3 || lw > 8 || lh < 0 || Ci % 32 || Co < 33) return p;
+  // 128- and 256-wide images: 128-pixel tiles (two rows x 64 columns), persistent kernel only
+  p.bn = lw > 6 ? 128 : 256;
+  p.rows2 = (lw > 6 && H >= 2) ? 1 : 0;
   const int WBh = p.rows2 ? 64 : (W < p.bn ? W : p.bn), NR = p.bn / WBh;
   p.SR = NR < H ? NR : H;
   p.NSEG = NR / p.SR;
@@ -716,7 +691,7 @@ FwdPlanP2 plan_fwd_p2(int B, int Ci, int H, int W, int Co, int KS, int ns) {
   p.nt = (int)(((long long)B * H * W + p.bn - 1) / p.bn);
   p.bm = Co <= 64 ? 64 : 128;
   // mid-sized layers: 64-row tiles when that fills the chip without split-K and 128-row tiles would not
-  if (p.bm == 128 && cdiv(Co, 128) * p.nt < 192 && cdiv(Co, 64) * p.nt >= 192 && p2_bm64_mid()) p.bm = 64;
+  if (p.bm == 128 && cdiv(Co, 128) * p.nt < 192 && cdiv(Co, 64) * p.nt >= 192) p.bm = 64;
   p.lds = ((size_t)3 * band_taps_per_stage(p.bm, p.bn, lw) * 2 * 4 * p.bm + (size_t)2 * 2 * 4 * p.PXB) * 16;   // [3][G] weight ring + 2 bands
   const size_t stage_bytes = p.bn == 256 ? (size_t)p.bm * (256 + 4) * sizeof(float) : 0;   // the staged epilogue's tile reuses the allocation
   if (p.lds < stage_bytes) p.lds = stage_bytes;
@@ -731,11 +706,7 @@ FwdPlanP2 plan_fwd_p2(int B, int Ci, int H, int W, int Co, int KS, int ns) {
     return p;
   }
   int splits = 1;
-  static int target = -1;   // blocks aimed at when K is split (ITCV_P2_BLOCKS overrides; diagnostic)
-  if (target < 0) {
-    const char* e = getenv("ITCV_P2_BLOCKS");
-    target = e ? atoi(e) : 256;
-  }
+  constexpr int target = 256;   // blocks aimed at when K is split: one per CU
   if (tiles < 192 && p.cpt >= 2) {
     splits = target / tiles;
     if (splits > p.cpt) splits = p.cpt;
@@ -747,23 +718,7 @@ FwdPlanP2 plan_fwd_p2(int B, int Ci, int H, int W, int Co, int KS, int ns) {
   return p;
 }
 
-static int band_persistent_blocks() {   // ITCV_BAND_PERSIST=0: one tile per block always (diagnostic); else the block count
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("ITCV_BAND_PERSIST");
-    v = e ? atoi(e) : 256;
-  }
-  return v;
-}
-
-static int band_w4() {   // ITCV_BAND_W4=1: four MFMA waves (64x64 blocks) in the persistent 64-row band kernel; slower, see there
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("ITCV_BAND_W4");
-    v = (e && e[0] == '1') ? 1 : 0;
-  }
-  return v;
-}
+static int band_persistent_blocks() { return g_opt.band_persist_blocks; }   // itcv_set_option("band_persist_blocks")
 
 template <int LOG2W, int BM, bool UP2>
 static void launch_fwd_p2_cfg(const ConvArgsP2& a, int splits, size_t lds, hipStream_t st) {
@@ -777,18 +732,6 @@ static void launch_fwd_p2_cfg(const ConvArgsP2& a, int splits, size_t lds, hipSt
   if (!a.stats && ids > band_persistent_blocks() && band_persistent_blocks() > 0) {
     // more tiles than CUs: persistent blocks (one per CU) that prefetch the next tile's band under the current MFMAs
     if (band_m16()) {
-      if constexpr (BM == 64) {
-        if (band_w4()) {
-          auto pk4 = conv_fwd_bf16p3_kernel<LOG2W, BM, UP2, 256, true, 4>;
-          static size_t pattr4 = 0;
-          if (pattr4 < lds) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pk4), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            pattr4 = lds;
-          }
-          launch_timed(pk4, dim3(band_persistent_blocks(), splits), dim3(512), lds, st, a);
-          return;
-        }
-      }
       auto pk = conv_fwd_bf16p3_kernel<LOG2W, BM, UP2, 256, true>;
       static size_t pattr16 = 0;
       if (pattr16 < lds) {
@@ -834,7 +777,7 @@ static void launch_fwd_p2_w(const ConvArgsP2& a, int bm, int up2, int splits, si
 // 128- / 256-wide images: the persistent kernel with 128-pixel tiles
 template <int LOG2W, int BM, bool UP2, bool M16, bool ROWS2>
 static void launch_fwd_p3_wide_k(const ConvArgsP2& a, int splits, size_t lds, hipStream_t st) {
-  auto pk = conv_fwd_bf16p3_kernel<LOG2W, BM, UP2, 128, M16, 8, ROWS2>;
+  auto pk = conv_fwd_bf16p3_kernel<LOG2W, BM, UP2, 128, M16, ROWS2>;
   static size_t pattr = 0;
   if (pattr < lds) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pk), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -874,7 +817,6 @@ bool band_is_persistent(const ConvArgsP2& a, const FwdPlanP2& p) {
 void launch_fwd_p2(const ConvArgsP2& a, const FwdPlanP2& p, int W, int up2, hipStream_t st) {
   if (p.bn == 128) {
     if (log2_exact(W) == 7) launch_fwd_p3_wide<7>(a, p.bm, up2, p.splits, p.lds, p.rows2, st);
-    else if (log2_exact(W) == 2) launch_fwd_p3_wide<2>(a, p.bm, up2, p.splits, p.lds, 0, st);
     else launch_fwd_p3_wide<8>(a, p.bm, up2, p.splits, p.lds, p.rows2, st);
     return;
   }

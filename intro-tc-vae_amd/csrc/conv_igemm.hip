@@ -361,193 +361,11 @@ struct ConvArgsB {
 #endif
 };
 
-template <int KS, int BM, int BN, int WM, int WN, bool UP2, int NS>
-__global__ __launch_bounds__(WM* WN * 64) void conv_fwd_bf16s_kernel(ConvArgsB a) {
-  constexpr int NT = WM * WN * 64, BK = 32, KC = BK / 8, P = KS / 2;
-  constexpr int WTM = BM / WM, WTN = BN / WN, TM = WTM / 32, TN = WTN / 32;
-  static_assert(NT == 256 && (BN == 128 || BN == 256), "loader mapping");
-  constexpr int ASZ = NS * KC * BM, BSZ = NS * KC * BN;
-  __shared__ u32x4 As[2 * ASZ];
-  __shared__ u32x4 Bs[2 * BSZ];
-
-  const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
-  const int wm = wid / WN, wn = wid % WN, l31 = lane & 31, half = lane >> 5;
-  const int bid = blockIdx.x, xcd = bid & 7, q = bid >> 3;
-  const int tile_m = q % a.mt, tile_n = (q / a.mt) * 8 + xcd;
-  if (tile_n >= a.nt) return;
-  const int sk = blockIdx.y;
-  const int kt0 = sk * a.ktiles_per_split;
-  const int kt1 = min(a.ktiles, kt0 + a.ktiles_per_split);
-  const int m0 = tile_m * BM, n0 = tile_n * BN;
-  const int H = a.H, W = a.W, HW = H * W;
-  const int Hs = UP2 ? H / 2 : H, Ws = UP2 ? W / 2 : W, HWs = Hs * Ws;
-
-  // ---- per-thread im2col column -------------------------------------------------------------
-  constexpr int BROWS = NT / BN;            // k groups of the tile split over thread rows (2 or 1)
-  constexpr int RPT = BK / BROWS;           // k rows per thread: 16 or 32
-  const int nl = t % BN;
-  const int kg = __builtin_amdgcn_readfirstlane(t / BN);   // this thread's rows: kg*RPT .. kg*RPT+RPT-1
-  const int n = n0 + nl;
-  const bool nvalid = n < a.N;
-  int bi = 0, h = 0, w = 0;
-  if (nvalid) {
-    bi = n / HW;
-    const int hw = n - bi * HW;
-    h = hw / W;
-    w = hw - h * W;
-  }
-  uint32_t tapmask = 0;
-#pragma unroll
-  for (int tap = 0; tap < KS * KS; ++tap) {
-    const int dh = tap / KS - P, dw = tap % KS - P;
-    if (nvalid && (unsigned)(h + dh) < (unsigned)H && (unsigned)(w + dw) < (unsigned)W) tapmask |= 1u << tap;
-  }
-  const int tb = bi * a.Ci * HWs + (UP2 ? 0 : h * W + w);
-  const __amdgpu_buffer_rsrc_t rx = make_rsrc(a.x, a.x_bytes);
-  const uint32_t hw4 = (uint32_t)HWs * 4u, row0_4 = (uint32_t)(kg * RPT) * hw4;
-
-  constexpr int AV = NS * KC * BM, AL = AV / NT;   // 16-byte chunks of the A tile per thread
-  static_assert(AV % NT == 0 && BM % 64 == 0, "A tile chunks must divide evenly, one wave stays inside a row block");
-  float breg[RPT];
-
-  // A tile (pre-split weights, already in LDS order): LDS-DMA straight from global memory, no VGPR
-  // staging and no ds_write -- the LDS store path (~79 B/clk/CU) is what this kernel is bound by.
-  auto dma_A = [&](int kt, int buf) {
-    const u32x4* wt = a.wp + (size_t)kt * NS * KC * a.Mp;
-#pragma unroll
-    for (int i = 0; i < AL; ++i) {
-      const int idx = t + i * NT, pk = idx / BM, ml = idx - pk * BM;   // pk = plane*KC + kc
-      const int wave_chunk = __builtin_amdgcn_readfirstlane((t & ~63) + i * NT);
-      __builtin_amdgcn_global_load_lds(
-          (const __attribute__((address_space(1))) void*)(wt + (size_t)pk * a.Mp + m0 + ml),
-          (__attribute__((address_space(3))) void*)(As + buf * ASZ + wave_chunk), 16, 0, 0);
-    }
-  };
-  auto load_tile = [&](int kt, int tap, int cib) {
-    const int dh = tap / KS - P, dw = tap - (tap / KS) * KS - P;
-    const bool valid = (tapmask >> tap) & 1u;
-    int off;
-    if (UP2)
-      off = tb + ((h + dh) >> 1) * Ws + ((w + dw) >> 1) + cib * BK * HWs;
-    else
-      off = tb + dh * W + dw + cib * BK * HWs;
-    const uint32_t voff = valid ? (uint32_t)off * 4u : kOobBase;
-#pragma unroll
-    for (int i = 0; i < RPT; ++i) breg[i] = buf_load_s(rx, voff, row0_4 + (uint32_t)i * hw4);
-  };
-  auto store_tile = [&](int buf) {
-    u32x4* Bd = Bs + buf * BSZ;
-#pragma unroll
-    for (int c = 0; c < RPT / 8; ++c) {
-      float v[8];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) v[j] = breg[c * 8 + j];
-      u32x4 pl[NS];
-      split8<NS>(v, pl);
-      const int kc = kg * (RPT / 8) + c;
-#pragma unroll
-      for (int p = 0; p < NS; ++p) Bd[(p * KC + kc) * BN + nl] = pl[p];
-    }
-  };
-
-  f32x16 acc[TM][TN];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  auto mfma_ks = [&](int buf, int ks) {
-    const u32x4* Ab = As + buf * ASZ;
-    const u32x4* Bb = Bs + buf * BSZ;
-    const int kc = ks * 2 + half;
-    bf16x8 af[NS][TM], bfr[NS][TN];
-#pragma unroll
-    for (int p = 0; p < NS; ++p) {
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-        af[p][i] = __builtin_bit_cast(bf16x8, Ab[(p * KC + kc) * BM + wm * WTM + i * 32 + l31]);
-#pragma unroll
-      for (int j = 0; j < TN; ++j)
-        bfr[p][j] = __builtin_bit_cast(bf16x8, Bb[(p * KC + kc) * BN + wn * WTN + j * 32 + l31]);
-    }
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        f32x16 c = acc[i][j];
-        if constexpr (NS == 3) {   // smallest terms first
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][i], bfr[1][j], c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bfr[2][j], c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2][i], bfr[0][j], c, 0, 0, 0);
-        }
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bfr[1][j], c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][i], bfr[0][j], c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bfr[0][j], c, 0, 0, 0);
-        acc[i][j] = c;
-      }
-  };
-
-  // Pipeline over K-tiles (two LDS buffers): iteration i computes tile i from LDS[cur] while
-  //   - the split + store of the im2col tile i+1 (gathered into registers during iteration i-1),
-  //   - the LDS-DMA of the weight tile i+1, and
-  //   - the global gather of im2col tile i+2
-  // are issued ahead of its MFMAs, so all memory traffic has the whole MFMA phase to land.  Past the
-  // end the gathers are range-checked to 0 and the unused stores are harmless: no branches in the loop.
-  if (kt0 < kt1) {
-    constexpr int KKc = KS * KS;   // channel-block outer, tap inner (vector-L1 reuse of the shifted windows)
-    int cib = kt0 / KKc, tap = kt0 - cib * KKc;
-    auto advance = [&]() {
-      if (++tap == KKc) tap = 0, ++cib;
-    };
-    dma_A(kt0, 0);
-    load_tile(kt0, tap, cib);
-    store_tile(0);
-    advance();
-    load_tile(min(kt0 + 1, kt1 - 1), tap, cib);
-    __syncthreads();
-    int cur = 0;
-    for (int kt = kt0; kt < kt1; ++kt) {
-      store_tile(cur ^ 1);                            // im2col tile kt+1: registers -> LDS
-      dma_A(min(kt + 1, kt1 - 1), cur ^ 1);           // weight tile kt+1: global -> LDS
-      advance();
-      load_tile(min(kt + 2, kt1 - 1), tap, cib);      // im2col tile kt+2: global -> registers
-      mfma_ks(cur, 0);
-      mfma_ks(cur, 1);
-      __syncthreads();
-      cur ^= 1;
-    }
-  }
-
-  float* out = a.y + (size_t)sk * a.slab_stride;
-#pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    const int nn = n0 + wn * WTN + j * 32 + l31;
-    if (nn >= a.N) continue;
-    const int b2 = nn / HW, hw2 = nn - b2 * HW;
-    const size_t base = (size_t)b2 * a.Co * HW + hw2;
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = m0 + wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-        if (m < a.Co) {
-          float v = acc[i][j][r];
-          if (a.bias) v += a.bias[m];
-          out[base + (size_t)m * HW] = v;
-        }
-      }
-    }
-  }
-}
-
-// Wave-specialised form of conv_fwd_bf16s_kernel: 512 threads = 4 consumer waves (one per SIMD) that
-// only read fragments and issue MFMAs + 4 producer waves that only gather / split / store the next
-// tiles.  Two identical 4-wave blocks sharing a SIMD run in lockstep (same program, same barriers): they
-// collide on the matrix pipe and then idle together (measured: 36 % MFMA busy, 42 % issue stalls).  A
-// producer wave next to a consumer wave uses the VALU / VMEM / LDS-store paths while the matrix pipe
-// of the same SIMD stays fed.
+// Wave-specialised: 512 threads = 4 consumer waves (one per SIMD) that only read fragments and issue MFMAs + 4
+// producer waves that only gather / split / store the next tiles.  (The first form of this kernel had every wave do
+// both: two identical 4-wave blocks sharing a SIMD ran in lockstep, collided on the matrix pipe and then idled
+// together -- measured 36 % MFMA busy, 42 % issue stalls; removed.)  A producer wave next to a consumer wave uses the
+// VALU / VMEM / LDS-store paths while the matrix pipe of the same SIMD stays fed.
 template <int KS, int BM, int BN, int WM, int WN, bool UP2, int NS>
 __global__ __launch_bounds__(512) void conv_fwd_bf16s_ws_kernel(ConvArgsB a) {
   constexpr int NP = 256, BK = 32, KC = BK / 8, P = KS / 2, KKc = KS * KS;
@@ -1983,14 +1801,7 @@ static WgPlan plan_wgrad(int B, int Ci, int H, int W, int Co, int KS) {
   p.tiles = p.mt * p.nt;
   p.ktiles = (int)((Ktot + 31) / 32);
   int splits = cdiv(768, p.tiles);
-  if (p.cb == 4) {   // one 128-column tile: a block per CU with long K slices; the slab reduce shrinks with the splits
-    static int s4 = -1;
-    if (s4 < 0) {
-      const char* e = getenv("ITCV_WG4_SPLITS");
-      s4 = e ? atoi(e) : 256;
-    }
-    splits = cdiv(s4, p.tiles);
-  }
+  if (p.cb == 4) splits = cdiv(256, p.tiles);   // one 128-column tile: a block per CU with long K slices; the slab reduce shrinks with the splits
   if (splits > p.ktiles / 8) splits = p.ktiles / 8;
   if (splits > 256) splits = 256;
   if (splits < 1) splits = 1;
@@ -2059,14 +1870,8 @@ static inline int pad32(int c) { return (c + 31) & ~31; }
 struct FwdPlanB {
   int bm, bn, mt, nt, cip, ktiles, splits, kps;
 };
-static int fwd_b_split_target() {   // blocks aimed at when K is split (ITCV_FWDB_BLOCKS overrides; diagnostic)
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("ITCV_FWDB_BLOCKS");
-    v = e ? atoi(e) : 256;   // one block per CU: half the slabs and prologues of a 512-block split (measured +2 % step)
-  }
-  return v;
-}
+// blocks aimed at when K is split: one block per CU -- half the slabs and prologues of a 512-block split (measured +2 % step)
+constexpr int kFwdBSplitTarget = 256;
 static FwdPlanB plan_fwd_b(int B, int Ci, int H, int W, int Co, int KS) {
   FwdPlanB p;
   const long long N = (long long)B * H * W;
@@ -2079,7 +1884,7 @@ static FwdPlanB plan_fwd_b(int B, int Ci, int H, int W, int Co, int KS) {
   const int tiles = p.mt * p.nt;
   int splits = 1;
   if (tiles < 192 && p.ktiles >= 8) {
-    splits = cdiv(fwd_b_split_target(), tiles);
+    splits = cdiv(kFwdBSplitTarget, tiles);
     if (splits > p.ktiles / 4) splits = p.ktiles / 4;
     if (splits > 64) splits = 64;
     if (splits < 1) splits = 1;
@@ -2089,45 +1894,16 @@ static FwdPlanB plan_fwd_b(int B, int Ci, int H, int W, int Co, int KS) {
   return p;
 }
 
-static int bf16s_ws() {
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("ITCV_BF16S_WS");
-    v = (e && e[0] == '0') ? 0 : 1;
-  }
-  return v;
-}
-
 template <int KS, int NS>
 static void launch_fwd_b(const ConvArgsB& a, int bm, int splits, int up2, hipStream_t st) {
-  dim3 grid(cdiv(a.nt, 8) * 8 * a.mt, splits), block(256);
-  if (bf16s_ws()) {
-    dim3 blk(512);
-    if (bm == 64) {
-      if (up2) launch_timed((conv_fwd_bf16s_ws_kernel<KS, 64, 256, 1, 4, true, NS>), grid, blk, 0, st, a);
-      else launch_timed((conv_fwd_bf16s_ws_kernel<KS, 64, 256, 1, 4, false, NS>), grid, blk, 0, st, a);
-    } else {
-      if (up2) launch_timed((conv_fwd_bf16s_ws_kernel<KS, 128, 128, 2, 2, true, NS>), grid, blk, 0, st, a);
-      else launch_timed((conv_fwd_bf16s_ws_kernel<KS, 128, 128, 2, 2, false, NS>), grid, blk, 0, st, a);
-    }
-    return;
-  }
+  dim3 grid(cdiv(a.nt, 8) * 8 * a.mt, splits), blk(512);
   if (bm == 64) {
-    if (up2) launch_timed((conv_fwd_bf16s_kernel<KS, 64, 256, 1, 4, true, NS>), grid, block, 0, st, a);
-    else launch_timed((conv_fwd_bf16s_kernel<KS, 64, 256, 1, 4, false, NS>), grid, block, 0, st, a);
+    if (up2) launch_timed((conv_fwd_bf16s_ws_kernel<KS, 64, 256, 1, 4, true, NS>), grid, blk, 0, st, a);
+    else launch_timed((conv_fwd_bf16s_ws_kernel<KS, 64, 256, 1, 4, false, NS>), grid, blk, 0, st, a);
   } else {
-    if (up2) launch_timed((conv_fwd_bf16s_kernel<KS, 128, 128, 2, 2, true, NS>), grid, block, 0, st, a);
-    else launch_timed((conv_fwd_bf16s_kernel<KS, 128, 128, 2, 2, false, NS>), grid, block, 0, st, a);
+    if (up2) launch_timed((conv_fwd_bf16s_ws_kernel<KS, 128, 128, 2, 2, true, NS>), grid, blk, 0, st, a);
+    else launch_timed((conv_fwd_bf16s_ws_kernel<KS, 128, 128, 2, 2, false, NS>), grid, blk, 0, st, a);
   }
-}
-
-static int bf16p_stages() {
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("ITCV_BF16P_STAGES");
-    v = (e && e[0] == '2') ? 2 : 3;
-  }
-  return v;
 }
 
 template <int KS, int BM, int BN, int WM, int WN, bool UP2, int NS, int NSTAGE>
@@ -2167,53 +1943,27 @@ static void launch_fwd_p_st(const ConvArgsP& a, int bm, int splits, int up2, hip
 }
 template <int KS, int NS>
 static void launch_fwd_p(const ConvArgsP& a, int bm, int splits, int up2, hipStream_t st) {
-  if constexpr (NS == 2) {
-    if (bf16p_stages() == 3) {
-      launch_fwd_p_st<KS, NS, 3>(a, bm, splits, up2, st);
-      return;
-    }
-  }
-  launch_fwd_p_st<KS, NS, 2>(a, bm, splits, up2, st);
+  launch_fwd_p_st<KS, NS, NS == 2 ? 3 : 2>(a, bm, splits, up2, st);   // ring depth: three stages where LDS allows (two planes)
 }
 
 struct WgPlanP {
   int bm, bn, tiles_m, tiles_n, steps, splits, sps;
   int kh;   // slabs per K slice (2 for the 64 x 64 tile: its wave groups keep separate slabs)
 };
-static int wgrad_p_small() {   // ITCV_WGP_SMALL=0: no 64 x 64 tile (diagnostic)
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("ITCV_WGP_SMALL");
-    v = (e && e[0] == '0') ? 0 : 1;
-  }
-  return v;
-}
-static int wgrad_p_wide() {   // ITCV_WGP_WIDE=0: 128 x 64 tiles only (diagnostic)
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("ITCV_WGP_WIDE");
-    v = (e && e[0] == '0') ? 0 : 1;
-  }
-  return v;
-}
 static WgPlanP plan_wgrad_p(int B, int Ci, int H, int W, int Co) {
   WgPlanP p;
   p.bm = (Co <= 64 && Ci >= 128) ? 64 : 128;    // 64 x 128 (co x ci) tiles when the output side is narrow
   p.bn = 8192 / p.bm;
   p.kh = 1;
   // 64 -> 64 channels: a 128-row tile would multiply 64 rows of zeros; 64 x 64 with the waves split over the k-steps
-  if (Co <= 64 && Ci <= 64 && wgrad_p_small()) p.bm = 64, p.bn = 64, p.kh = 2;
+  if (Co <= 64 && Ci <= 64) p.bm = 64, p.bn = 64, p.kh = 2;
   // 128 x 128 tiles halve the operand bytes per MFMA (the 128 x 64 form runs near the ~30 B/clk/CU ingest limit) but
   // double the slab a block writes: measured faster only for the widest layers, where few K slices are needed
-  if (p.bm == 128 && Ci >= 512 && Co >= 256 && W >= 8 && wgrad_p_wide()) p.bn = 128;
+  if (p.bm == 128 && Ci >= 512 && Co >= 256 && W >= 8) p.bn = 128;
   p.tiles_m = cdiv(Co, p.bm), p.tiles_n = cdiv(Ci, p.bn);
   p.steps = (int)(((long long)B * H * W) / 64);
   const int T = p.tiles_m * p.tiles_n * 3;
-  static int target = -1;   // blocks aimed at (ITCV_WGP_BLOCKS overrides; diagnostic): one 768-thread block per CU
-  if (target < 0) {
-    const char* e = getenv("ITCV_WGP_BLOCKS");
-    target = e ? atoi(e) : 256;
-  }
+  constexpr int target = 256;   // blocks aimed at: one 768-thread block per CU
   // blocks are launched in runs of 24 (8 (tile, K slice) groups x 3 filter rows, see the kernel): keep the padded grid
   // within one block per CU
   int splits = (8 * (target / 24)) / (T / 3);

@@ -8,8 +8,9 @@
 namespace itcv {
 
 // Diagnostic instrumentation (operand ablation, in-kernel cycle stamps) exists only in -DITCV_DIAG builds
-// (`make diag`, used by tools/abl.sh): in the shipped library the tests below are the constant 0, the branches are
-// compiled out and no environment variable can alter results.
+// (`make diag`, used by tools/abl.sh): in the shipped library the tests below are the constant 0 and the branches are
+// compiled out.  The shipped library reads NO environment variable: the two launch-shape choices that remain selectable
+// are explicit, validated options (itcv_set_option, include/itcv_hip.h), each exercised by the test matrix.
 #ifdef ITCV_DIAG
 #define ITCV_ABL(args, bits) (((args).ablate & (bits)) != 0)
 #define ITCV_DBG(args) ((args).debug != 0)
@@ -76,9 +77,8 @@ struct ConvArgsP2 {
 };
 
 // taps (K-tiles) per barrier stage of the band kernels: tiles with little MFMA work per tap take two
-// (the 4-pixel-wide 128-row form keeps one tap per stage: two would not fit LDS next to its 8-segment bands)
-__host__ __device__ constexpr int band_taps_per_stage(int bm, int bn, int lw) {
-  return (bm == 64 || (bn == 128 && lw != 2)) ? 2 : 1;
+__host__ __device__ constexpr int band_taps_per_stage(int bm, int bn, int /*lw*/) {
+  return (bm == 64 || bn == 128) ? 2 : 1;
 }
 
 // MFMA shape of the band kernels' inner product.  The chip lowers its clock under dense bf16 MFMA loops and holds a
@@ -106,17 +106,19 @@ struct BandMfma<true> {
   static __device__ __forceinline__ int row(int r, int kq) { return 4 * kq + r; }
 };
 
-// v_mfma_f32_16x16x32_bf16 in the band kernels and the 128-pixel planes kernel (default; ITCV_BAND_M16=0: 32x32x16).  Same-box A/B of the c2 step:
-// 16.02 -> 15.75 ms, the 64 -> 64 @ 64x64 launch 104 -> 96 us.  Launches that produce BatchNorm tile statistics keep the
-// 32x32x16 instantiation (its staged epilogue is written for that accumulator layout).
-inline int band_m16() {
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("ITCV_BAND_M16");
-    v = (e && e[0] == '0') ? 0 : 1;
-  }
-  return v;
-}
+// Options (itcv_set_option): process-wide, read at launch time.
+//   band_m16             1 (default): v_mfma_f32_16x16x32_bf16 in the band kernels and the 128-pixel planes kernel; 0: 32x32x16.
+//                        Same-box A/B of the c2 step: 16.02 -> 15.75 ms, the 64 -> 64 @ 64x64 launch 104 -> 96 us.  Launches that
+//                        produce BatchNorm tile statistics always use the 32x32x16 instantiation (its staged epilogue is
+//                        written for that accumulator layout).
+//   band_persist_blocks  256 (default): block count of the persistent band kernel, used when a launch has more tiles than
+//                        that; 0: one tile per block always.  Any value gives bit-identical results (tests).
+struct Options {
+  int band_m16 = 1;
+  int band_persist_blocks = 256;
+};
+extern Options g_opt;
+inline int band_m16() { return g_opt.band_m16; }
 
 struct FwdPlanP2 {
   int ok, bm, bn, mt, nt, cpt, splits, cps, SR, NSEG, NP, NPC, PXB;

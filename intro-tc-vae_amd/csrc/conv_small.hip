@@ -485,25 +485,15 @@ int itcv_conv2d_small_cin_fwd_bf16x3(const float* x, const float* w, const float
   const int njobs = B * row_blocks * strips;
   hipStream_t st = S(stream);
   ProfScope prof(st, 5, KS, C, 0, 2, 2.0 * B * H * W * (double)Co * C * KS * KS);
-  // ITCV_SCIN_AHEAD=1: request each input row one output row ahead of its use (diagnostic).  Measured slower
-  // (37 -> 43 us at 128 x 3 x 64 x 64): the kernel is bound by its 134 MB of stores, and the longer ring costs registers.
-  static int ahead = -1;
-  if (ahead < 0) {
-    const char* e = getenv("ITCV_SCIN_AHEAD");
-    ahead = (e && e[0] == '1') ? 1 : 0;
-  }
-#define ITCV_SCIN_K(CI_, DG_, AH_)                                                                                    \
-  launch_timed((conv_small_cin_mfma_kernel<CI_, DG_, AH_>), dim3(cdiv(njobs, 4)), dim3(256), 0, st, x, w, bias, y, H, W, \
+  // (Requesting each input row one output row ahead of its use -- AHEAD = 1 -- was measured slower, 37 -> 43 us at
+  // 128 x 3 x 64 x 64: the kernel is bound by its 134 MB of stores, and the longer ring costs registers.)
+#define ITCV_SCIN_K(CI_, DG_)                                                                                       \
+  launch_timed((conv_small_cin_mfma_kernel<CI_, DG_, 0>), dim3(cdiv(njobs, 4)), dim3(256), 0, st, x, w, bias, y, H, W, \
                strips, row_blocks, RB, njobs)
-#define ITCV_SCIN_M(CI_)                                        \
-  do {                                                          \
-    if (for_dgrad) {                                            \
-      if (ahead) ITCV_SCIN_K(CI_, true, 1);                     \
-      else ITCV_SCIN_K(CI_, true, 0);                           \
-    } else {                                                    \
-      if (ahead) ITCV_SCIN_K(CI_, false, 1);                    \
-      else ITCV_SCIN_K(CI_, false, 0);                          \
-    }                                                           \
+#define ITCV_SCIN_M(CI_)                   \
+  do {                                     \
+    if (for_dgrad) ITCV_SCIN_K(CI_, true); \
+    else ITCV_SCIN_K(CI_, false);          \
   } while (0)
   if (C == 1) ITCV_SCIN_M(1);
   else if (C == 2) ITCV_SCIN_M(2);

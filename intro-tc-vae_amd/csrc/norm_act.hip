@@ -837,45 +837,13 @@ static inline int grid_for(size_t n, int per_thread = 1) {
   return b < 1 ? 1 : (int)b;
 }
 
-// Which plane-store form the apply kernels use (see store_planes_wave): bit 0 forward, bit 1 backward with the gradient at
-// the same resolution, bit 2 backward through the pooling / upsampling adjoints.  ITCV_BN_STRIP overrides (diagnostic).
-static inline int bn_strip_mask() {
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("ITCV_BN_STRIP");
-    // measured on one box, whole c2 step (20 graph replays): mask 0: 19.75 ms, 1: 19.55, 5: 19.40, 7: 19.30.  (With
-    // cold caches -- tools/bn_bench.py flushes them -- the same-resolution backward is slower with the strip, the forward
-    // 61 -> 51 us: inside a step the tensors are partly cache resident and the store side matters more.)
-    v = e ? atoi(e) : 7;
-  }
-  return v;
-}
-
-static inline bool bn_merge_groups() {   // ITCV_BN_MERGE_GROUPS=0: one launch per BatchNorm group always (diagnostic)
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("ITCV_BN_MERGE_GROUPS");
-    v = (e && e[0] == '0') ? 0 : 1;
-  }
-  return v != 0;
-}
-
-static inline bool bn_fuse_finalize() {   // ITCV_BN_FUSE=0: always finalise in a separate launch (diagnostic)
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("ITCV_BN_FUSE");
-    v = (e && e[0] == '0') ? 0 : 1;
-  }
-  return v != 0;
-}
-
+// Plane stores of the apply kernels always go through the wave-private LDS strip (store_planes_wave): measured on one
+// box, whole c2 step, against direct stores: 19.75 -> 19.30 ms.  All BatchNorm groups of a layer are issued together and
+// the apply pass folds the per-slice partial sums itself where a thread block covers whole channel groups (the one-launch-
+// per-group and separate-finalize forms of round 2 were diagnostics and are gone).
 static inline int bn_splits(int B, int C, int HW) {
   const size_t total = (size_t)B * HW;
-  static int target = -1;   // blocks aimed at by the sliced reductions (ITCV_BN_BLOCKS overrides; diagnostic)
-  if (target < 0) {
-    const char* e = getenv("ITCV_BN_BLOCKS");
-    target = e ? atoi(e) : 1024;
-  }
+  constexpr int target = 1024;   // blocks aimed at by the sliced reductions
   int s = cdiv(target, C);
   const size_t maxs = cdivz(total, 1024);
   if ((size_t)s > maxs) s = (int)maxs;
@@ -969,11 +937,7 @@ int itcv_bn_act_fwd(const float* x, const float* mean, const float* rstd, const 
     const size_t pstride = plane_stride ? plane_stride : (size_t)B * (C / 8) * (pool ? (H / 2) * (W / 2) : H * W);
 #define ITCV_FWD_PLANES(POOL_, NS_)                                                                                   \
   do {                                                                                                                \
-    if (bn_strip_mask() & 1)                                                                                          \
       hipLaunchKernelGGL((bn_act_fwd_planes_kernel<POOL_, NS_, false, true>), grid, blk, 0, S(stream), x, mean, rstd, gamma, \
-                         beta, skip, y, pl, B, C, H, W, slope, BnStatsIn{}, pstride, BnGrp{});                                   \
-    else                                                                                                              \
-      hipLaunchKernelGGL((bn_act_fwd_planes_kernel<POOL_, NS_, false, false>), grid, blk, 0, S(stream), x, mean, rstd, gamma, \
                          beta, skip, y, pl, B, C, H, W, slope, BnStatsIn{}, pstride, BnGrp{});                                   \
   } while (0)
     if (pool) {
@@ -1063,11 +1027,7 @@ int itcv_bn_act_bwd_apply(const float* x, const float* dy, const float* mean, co
     u32x4* pl = static_cast<u32x4*>(dx_planes);
 #define ITCV_BWD_PLANES(MODE_, NS_)                                                                              \
   do {                                                                                                           \
-    if (bn_strip_mask() & ((MODE_) == 0 ? 2 : 4))                                                                \
       hipLaunchKernelGGL((bn_bwd_apply_planes<MODE_, NS_, false, true>), grid, blk, 0, st, x, dy, mean, rstd, gamma, beta, \
-                         skip, dsums, count, dx, dskip, pl, B, C, H, W, slope, wsh, BnBwdSumsIn{}, pstride, BnGrp{});       \
-    else                                                                                                         \
-      hipLaunchKernelGGL((bn_bwd_apply_planes<MODE_, NS_, false, false>), grid, blk, 0, st, x, dy, mean, rstd, gamma, beta, \
                          skip, dsums, count, dx, dskip, pl, B, C, H, W, slope, wsh, BnBwdSumsIn{}, pstride, BnGrp{});       \
   } while (0)
 #define ITCV_BWD_PLANES_NS(MODE_)        \
@@ -1132,7 +1092,7 @@ int itcv_bn_train_fwd(const float* x, const float* gamma, const float* beta, con
     const size_t xs = (size_t)B * C * HWg, os = (size_t)B * C * HWo, ps = (size_t)B * (C / 8) * HWo;
     const int gsplits = bn_splits(B, C, HWg);
     const bool mergeable = !tile_stats && planes && (ns == 2 || ns == 3) && itcv_bn_act_planes_supported(C, H, W, pool) &&
-                           xs < (1ull << 31) && bn_merge_groups();
+                           xs < (1ull << 31);
     const bool merged = mergeable && gsplits == 1;
     if (mergeable && gsplits > 1 && ws && ws_bytes >= (size_t)groups * gsplits * 2 * C * sizeof(double)) {
       // large layers: sliced statistics of all groups in one launch (group = blockIdx.z), a fold that finalises the groups
@@ -1143,7 +1103,7 @@ int itcv_bn_train_fwd(const float* x, const float* gamma, const float* beta, con
                          HWg, gsplits, ilog2_exact(HWg), BnFinal{}, grp);
       ITCV_CHECK_LAUNCH("itcv_bn_train_fwd(grouped partials)");
       const int per_plane_g = pool ? (HWg / 4) / 2 : HWg / 4;
-      const bool fold_in_apply = per_plane_g >= 64 && bn_fuse_finalize();   // the apply pass folds the partial sums itself
+      const bool fold_in_apply = per_plane_g >= 64;   // the apply pass folds the partial sums itself
       if (!fold_in_apply) {
         hipLaunchKernelGGL(bn_combine_finalize_groups_kernel, dim3(cdiv(C, 256)), dim3(256), 0, S(stream), part, gsplits,
                            groups, (double)B * HWg, eps, momentum, running_mean, running_var, num_batches_tracked, mean, rstd,
@@ -1155,18 +1115,15 @@ int itcv_bn_train_fwd(const float* x, const float* gamma, const float* beta, con
       const size_t threads = (size_t)B * (C / 8) * (HWo / (pool ? 2 : 4));
       const dim3 grid(grid_for(threads), 1, groups), blk(256);
       u32x4* pl = static_cast<u32x4*>(planes);
-      const bool strip = bn_strip_mask() & 1;
 #define ITCV_FWD_GRP2_K(POOL_, NS_, ST_, STRIP_)                                                                          \
   hipLaunchKernelGGL((bn_act_fwd_planes_kernel<POOL_, NS_, ST_, STRIP_>), grid, blk, 0, S(stream), x, mean, rstd, gamma, beta, \
                      skip, y, pl, B, C, H, W, slope, (ST_) ? stg : BnStatsIn{}, plane_stride, grp)
 #define ITCV_FWD_GRP2(POOL_, NS_)                                                                                         \
   do {                                                                                                                    \
     if (fold_in_apply) {                                                                                                  \
-      if (strip) ITCV_FWD_GRP2_K(POOL_, NS_, true, true);                                                                 \
-      else ITCV_FWD_GRP2_K(POOL_, NS_, true, false);                                                                      \
+      ITCV_FWD_GRP2_K(POOL_, NS_, true, true);                                                                 \
     } else {                                                                                                              \
-      if (strip) ITCV_FWD_GRP2_K(POOL_, NS_, false, true);                                                                \
-      else ITCV_FWD_GRP2_K(POOL_, NS_, false, false);                                                                     \
+      ITCV_FWD_GRP2_K(POOL_, NS_, false, true);                                                                \
     }                                                                                                                     \
   } while (0)
       if (pool) {
@@ -1199,14 +1156,9 @@ int itcv_bn_train_fwd(const float* x, const float* gamma, const float* beta, con
     const size_t threads = (size_t)B * (C / 8) * (HWo / (pool ? 2 : 4));
     const dim3 grid(grid_for(threads), 1, groups), blk(256);
     u32x4* pl = static_cast<u32x4*>(planes);
-    const bool strip = bn_strip_mask() & 1;
 #define ITCV_FWD_GRP(POOL_, NS_)                                                                                          \
   do {                                                                                                                    \
-    if (strip)                                                                                                            \
       hipLaunchKernelGGL((bn_act_fwd_planes_kernel<POOL_, NS_, false, true>), grid, blk, 0, S(stream), x, mean, rstd, gamma,   \
-                         beta, skip, y, pl, B, C, H, W, slope, BnStatsIn{}, plane_stride, grp);                             \
-    else                                                                                                                  \
-      hipLaunchKernelGGL((bn_act_fwd_planes_kernel<POOL_, NS_, false, false>), grid, blk, 0, S(stream), x, mean, rstd, gamma,  \
                          beta, skip, y, pl, B, C, H, W, slope, BnStatsIn{}, plane_stride, grp);                             \
   } while (0)
     if (pool) {
@@ -1231,7 +1183,7 @@ int itcv_bn_train_fwd(const float* x, const float* gamma, const float* beta, con
   const int HW = H * W, splits = bn_splits(B, C, HW);
   const int per_plane = pool ? (HW / 4) / 2 : HW / 4;
   const bool fusable = planes && (ns == 2 || ns == 3) && itcv_bn_act_planes_supported(C, H, W, pool) && splits > 1 &&
-                       per_plane >= 64 && (size_t)B * C * HW < (1ull << 31) && bn_fuse_finalize();
+                       per_plane >= 64 && (size_t)B * C * HW < (1ull << 31);
   if (!fusable) {
     if (int e = itcv_bn_train_stats(x, B, C, HW, eps, momentum, running_mean, running_var, num_batches_tracked, mean,
                                     rstd, ws, ws_bytes, stream))
@@ -1249,11 +1201,7 @@ int itcv_bn_train_fwd(const float* x, const float* gamma, const float* beta, con
   u32x4* pl = static_cast<u32x4*>(planes);
 #define ITCV_FWD_FUSED(POOL_, NS_)                                                                                   \
   do {                                                                                                                \
-    if (bn_strip_mask() & 1)                                                                                          \
       hipLaunchKernelGGL((bn_act_fwd_planes_kernel<POOL_, NS_, true, true>), grid, blk, 0, S(stream), x, mean, rstd, gamma,  \
-                         beta, skip, y, pl, B, C, H, W, slope, st, pstride, BnGrp{});                                            \
-    else                                                                                                              \
-      hipLaunchKernelGGL((bn_act_fwd_planes_kernel<POOL_, NS_, true, false>), grid, blk, 0, S(stream), x, mean, rstd, gamma, \
                          beta, skip, y, pl, B, C, H, W, slope, st, pstride, BnGrp{});                                            \
   } while (0)
   if (pool) {
@@ -1281,8 +1229,7 @@ int itcv_bn_train_bwd(const float* x, const float* dy, const float* mean, const 
     const size_t xs = (size_t)B * C * HWg, dys = pool ? xs / 4 : (up2 ? xs * 4 : xs), ps = (size_t)B * (C / 8) * HWg;
     const bool vecg = (W % 4 == 0) && xs < (1ull << 31);
     const int gsplits = bn_splits(B, C, HWg);
-    const bool mergeable = vecg && dx_planes && (ns == 2 || ns == 3) && itcv_bn_act_planes_supported(C, H, W, 0) &&
-                           bn_merge_groups();
+    const bool mergeable = vecg && dx_planes && (ns == 2 || ns == 3) && itcv_bn_act_planes_supported(C, H, W, 0) ;
     const bool merged = mergeable && gsplits == 1;
     if (mergeable && gsplits > 1 && ws && ws_bytes >= (size_t)groups * gsplits * 2 * C * sizeof(double)) {
       if (pool) ITCV_REQUIRE(H % 2 == 0 && W % 2 == 0, "itcv_bn_train_bwd(pool)");
@@ -1293,7 +1240,7 @@ int itcv_bn_train_bwd(const float* x, const float* dy, const float* mean, const 
       const dim3 rgrid(C, gsplits, groups), agrid(grid_for(xs / 32), 1, groups), blk(256);
       u32x4* pl = static_cast<u32x4*>(dx_planes);
       const double count = (double)B * HWg;
-      const bool fold_in_apply = HWg / 4 >= 64 && bn_fuse_finalize();   // the apply pass folds the partial sums itself
+      const bool fold_in_apply = HWg / 4 >= 64;   // the apply pass folds the partial sums itself
       const BnBwdSumsIn smg{part, gsplits, dsums, dgamma, dbeta, accumulate};
 #define ITCV_BWD_GRP2_K(MODE_, NS_, SUMS_, STRIP_)                                                                       \
   hipLaunchKernelGGL((bn_bwd_apply_planes<MODE_, NS_, SUMS_, STRIP_>), agrid, blk, 0, st, x, dy, mean, rstd, gamma, beta,  \
@@ -1303,15 +1250,12 @@ int itcv_bn_train_bwd(const float* x, const float* dy, const float* mean, const 
   do {                                                                                                                   \
     hipLaunchKernelGGL((bn_bwd_partial_v4<MODE_, false>), rgrid, dim3(kRedThreads), 0, st, x, dy, mean, rstd, gamma, beta,  \
                        skip, part, B, C, H, W, slope, gsplits, wsh, hwsh, BnBwdFinal{}, grp);                            \
-    const bool strip_ = bn_strip_mask() & ((MODE_) == 0 ? 2 : 4);                                                        \
     if (fold_in_apply) {                                                                                                 \
-      if (strip_) ITCV_BWD_GRP2_K(MODE_, NS_, true, true);                                                               \
-      else ITCV_BWD_GRP2_K(MODE_, NS_, true, false);                                                                     \
+      ITCV_BWD_GRP2_K(MODE_, NS_, true, true);                                                               \
     } else {                                                                                                             \
       hipLaunchKernelGGL(bn_combine_param_groups_kernel, dim3(cdiv(C, 256)), dim3(256), 0, st, part, dsums, C, gsplits,   \
                          groups, dgamma, dbeta, accumulate);                                                             \
-      if (strip_) ITCV_BWD_GRP2_K(MODE_, NS_, false, true);                                                              \
-      else ITCV_BWD_GRP2_K(MODE_, NS_, false, false);                                                                    \
+      ITCV_BWD_GRP2_K(MODE_, NS_, false, true);                                                              \
     }                                                                                                                    \
   } while (0)
 #define ITCV_BWD_GRP2_NS(MODE_)            \
@@ -1351,11 +1295,7 @@ int itcv_bn_train_bwd(const float* x, const float* dy, const float* mean, const 
   do {                                                                                                                   \
     hipLaunchKernelGGL((bn_bwd_partial_v4<MODE_, true>), rgrid, dim3(kRedThreads), 0, st, x, dy, mean, rstd, gamma, beta,   \
                        skip, static_cast<double*>(nullptr), B, C, H, W, slope, 1, wsh, hwsh, bf, grp);                   \
-    if (bn_strip_mask() & ((MODE_) == 0 ? 2 : 4))                                                                        \
       hipLaunchKernelGGL((bn_bwd_apply_planes<MODE_, NS_, false, true>), agrid, blk, 0, st, x, dy, mean, rstd, gamma, beta,  \
-                         skip, dsums, count, dx, dskip, pl, B, C, H, W, slope, wsh, BnBwdSumsIn{}, plane_stride, grp);     \
-    else                                                                                                                 \
-      hipLaunchKernelGGL((bn_bwd_apply_planes<MODE_, NS_, false, false>), agrid, blk, 0, st, x, dy, mean, rstd, gamma, beta, \
                          skip, dsums, count, dx, dskip, pl, B, C, H, W, slope, wsh, BnBwdSumsIn{}, plane_stride, grp);     \
   } while (0)
 #define ITCV_BWD_GRP_NS(MODE_)            \
@@ -1375,7 +1315,7 @@ int itcv_bn_train_bwd(const float* x, const float* dy, const float* mean, const 
   const size_t n = (size_t)B * C * HW;
   const bool vec = (W % 4 == 0) && n < (1ull << 31);
   const bool fusable = dx_planes && (ns == 2 || ns == 3) && vec && itcv_bn_act_planes_supported(C, H, W, 0) &&
-                       splits > 1 && HW / 4 >= 64 && bn_fuse_finalize();
+                       splits > 1 && HW / 4 >= 64;
   if (!fusable) {
     if (int e = itcv_bn_act_bwd_reduce(x, dy, mean, rstd, gamma, beta, skip, dsums, dgamma, dbeta, accumulate, B, C, H, W,
                                        slope, pool, up2, ws, ws_bytes, stream))
@@ -1397,12 +1337,7 @@ int itcv_bn_train_bwd(const float* x, const float* dy, const float* mean, const 
   do {                                                                                                                \
     hipLaunchKernelGGL((bn_bwd_partial_v4<MODE_, false>), rgrid, dim3(kRedThreads), 0, st, x, dy, mean, rstd, gamma,   \
                        beta, skip, part, B, C, H, W, slope, splits, wsh, hwsh, BnBwdFinal{}, BnGrp{});                         \
-    if (bn_strip_mask() & ((MODE_) == 0 ? 2 : 4))                                                                     \
       hipLaunchKernelGGL((bn_bwd_apply_planes<MODE_, NS_, true, true>), agrid, blk, 0, st, x, dy, mean, rstd, gamma, beta, \
-                         skip, static_cast<const double*>(nullptr), count, dx, dskip, pl, B, C, H, W, slope, wsh, sm,   \
-                         pstride, BnGrp{});                                                                                     \
-    else                                                                                                              \
-      hipLaunchKernelGGL((bn_bwd_apply_planes<MODE_, NS_, true, false>), agrid, blk, 0, st, x, dy, mean, rstd, gamma, beta, \
                          skip, static_cast<const double*>(nullptr), count, dx, dskip, pl, B, C, H, W, slope, wsh, sm,   \
                          pstride, BnGrp{});                                                                                     \
   } while (0)

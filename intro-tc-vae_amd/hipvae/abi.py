@@ -28,6 +28,8 @@ p, i32, i64, sz, f32, f64 = (ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctyp
 SIGNATURES = {
     "itcv_abi_version": (i32, []),
     "itcv_last_error": (ctypes.c_char_p, []),
+    "itcv_set_option": (i32, [ctypes.c_char_p, i32]),
+    "itcv_get_option": (i32, [ctypes.c_char_p]),
     "itcv_profile_begin": (i32, []),
     "itcv_profile_end": (i32, []),
     "itcv_profile_get": (i32, [i32, p, p, p]),

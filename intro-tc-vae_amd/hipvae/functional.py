@@ -8,7 +8,6 @@ into Sync-BN (all-reduce of the fp64 channel moments over RCCL) for data-paralle
 with the full-batch reference.
 """
 import contextlib
-import os as _os
 import weakref
 
 import torch
@@ -20,6 +19,26 @@ from . import abi
 from .abi import call, lib, ptr, stream
 
 F32 = torch.float32
+
+
+def set_option(name, value):
+    """Launch-shape options of the library (include/itcv_hip.h: itcv_set_option): 'band_m16' (0/1),
+    'band_persist_blocks' (0 = one tile per block, else the persistent kernel's block count).  Validated by the library."""
+    call("itcv_set_option", name.encode(), int(value))
+
+
+def get_option(name):
+    return lib.itcv_get_option(name.encode())
+
+
+@contextlib.contextmanager
+def option_scope(name, value):
+    prev = get_option(name)
+    set_option(name, value)
+    try:
+        yield
+    finally:
+        set_option(name, prev)
 
 
 def _ws(nbytes, device):
@@ -54,45 +73,9 @@ def _grad_target(param):
     return g if (g is not None and g.is_contiguous() and g.dtype == F32) else None
 
 
-# ------------------------------------------------------------------ side stream for weight gradients
-# A step is ~1700 launches, many of them a few microseconds of work that leave the chip idle.  In
-# direct-accumulation mode the weight-gradient GEMMs (+ their slab reduces) depend only on the operand
-# planes, not on the activation-gradient chain, so they run on a second HIP stream and fill those gaps;
-# under stream capture this becomes a fork/join branch of the step's hipGraph.  side_join() makes the
-# current stream wait for them (called by the solvers right after loss.backward()).
-# Round 2: OFF by default.  With the batched passes the weight-gradient GEMMs fill the chip on their own (one block per
-# CU, the three filter-row blocks of a tile co-located on an XCD), and running them beside the data-gradient chain costs
-# more than the gaps it fills: same-box A/B of the c2 step 18.45 (on) vs 18.0 ms (off).  ITCV_WGRAD_STREAM=1 restores it.
-_SIDE = {"enabled": _os.environ.get("ITCV_WGRAD_STREAM", "0") == "1", "stream": None, "dirty": False}
-
-
-def set_wgrad_stream(flag):
-    _SIDE["enabled"] = bool(flag)
-
-
-@contextlib.contextmanager
-def _on_side_stream(device, keep):
-    """Run the block on the side stream, ordered after everything issued so far on the current stream;
-    ``keep``: tensors allocated on the current stream that the block reads (their memory must outlive it)."""
-    main = torch.cuda.current_stream(device)
-    side = _SIDE["stream"]
-    if side is None or side.device != device:
-        side = _SIDE["stream"] = torch.cuda.Stream(device=device)
-    side.wait_stream(main)
-    with torch.cuda.stream(side):
-        yield
-    for t in keep:
-        if t is not None:
-            t.record_stream(side)
-    _SIDE["dirty"] = True
-
-
-def side_join():
-    """Order the current stream after all weight-gradient work issued on the side stream."""
-    if _SIDE["dirty"]:
-        torch.cuda.current_stream().wait_stream(_SIDE["stream"])
-        _SIDE["dirty"] = False
-
+# (Round 1 issued the weight-gradient GEMMs on a second HIP stream; with the batched passes of round 2 they fill the chip
+# on their own and running them beside the data-gradient chain cost more than the gaps it filled -- same-box A/B of the c2
+# step 18.45 vs 18.0 ms -- so the side stream is gone.)
 
 # ------------------------------------------------------------------ convolution / linear
 _WEIGHT_EPOCH = [0]
@@ -113,16 +96,17 @@ def bump_weight_epoch(params=None):
         _PARAM_EPOCH[id(p)] = _PARAM_EPOCH.get(id(p), 0) + 1
 
 
+_NS = {"fp32": 0, "bf16x3": 2, "bf16x6": 3}
 import os as _os
 
-_NS = {"fp32": 0, "bf16x3": 2, "bf16x6": 3}
-_CONV_MATH = [_os.environ.get("ITCV_CONV_MATH", "fp32")]
+_CONV_MATH = [_os.environ.get("ITCV_CONV_MATH", "fp32")]   # the one documented environment override (with ITCV_DDP_GRAPH, ITCV_LIB)
 assert _CONV_MATH[0] in _NS, "ITCV_CONV_MATH must be one of fp32 / bf16x3 / bf16x6"
 
 
-_SMALL_PLANES = [_os.environ.get("ITCV_SMALL_PLANES", "1") != "0"]   # matrix-core form of the 3-output 5x5 convs
-_POISON = [_os.environ.get("ITCV_POISON", "0") == "1"]   # diagnostic: fill planes-only tensors with NaN
-_PLANES = [_os.environ.get("ITCV_PLANES", "1") != "0"]   # split-bf16 convs take pre-split operands (LDS-DMA kernels)
+# Module switches used by the test matrix (never read from the environment):
+_SMALL_PLANES = [True]   # matrix-core form of the 3-output 5x5 convs (tests compare it with the direct fp32 kernels)
+_POISON = [False]        # fill planes-only tensors with NaN (tests: nothing may read an fp32 tensor that was not written)
+_PLANES = [True]         # split-bf16 convs take pre-split operands (tests: planes kernels == gather kernels, bit for bit)
 
 
 def set_conv_math(mode):
@@ -185,8 +169,8 @@ def packed_weight(weight, w4, for_dgrad, ns=0):
     return wp
 
 
-# One launch re-packs every split-bf16 conv weight of a parameter group (ITCV_PACK_BATCH=0: one launch per layer).
-_PACK_BATCH = [_os.environ.get("ITCV_PACK_BATCH", "1") != "0"]
+# One launch re-packs every split-bf16 conv weight of a parameter group (False: one launch per layer; the tests compare the two).
+_PACK_BATCH = [True]
 _PACK_GROUPS = {}
 
 
@@ -258,9 +242,9 @@ def pack_weight_bf16s(w4, for_dgrad, ns):
     return wp
 
 
-# bf16x3 mode: the 3 -> 64 stem conv and the prediction layer's data-gradient on the matrix cores (ITCV_SCIN_MFMA=0: the
-# direct fp32 kernel, as in the other arithmetic modes)
-_SCIN_MFMA = [_os.environ.get("ITCV_SCIN_MFMA", "1") != "0"]
+# bf16x3 mode: the 3 -> 64 stem conv and the prediction layer's data-gradient on the matrix cores (False: the direct fp32
+# kernel, as in the other arithmetic modes; the tests compare the two)
+_SCIN_MFMA = [True]
 
 
 def conv_apply(x, weight, w4, for_dgrad, bias, B, Ci, H, W, Co, KS, up2):
@@ -311,7 +295,8 @@ def split_planes(x, ns):
 # BatchNorm statistics from the conv epilogue (itcv_conv2d_fwd_bf16p_st).  OFF by default: measured, the staged epilogue
 # that produces them costs the band kernel more (+8 % on the 64-channel layers) than the statistics pass it replaces
 # saves -- that pass reads the conv output out of the Infinity Cache right behind the conv (4-10 us) -- see DESIGN.md.
-_FUSE_STATS = [_os.environ.get("ITCV_FUSE_BN_STATS", "0") == "1"]
+# Kept as a tested option of the C ABI (itcv_conv2d_fwd_bf16p_st), not reachable from the environment.
+_FUSE_STATS = [False]
 
 
 def conv_apply_planes(xp, weight, w4, for_dgrad, bias, B, Ci, H, W, Co, KS, up2, ns, want_stats=False):
@@ -611,10 +596,7 @@ class Conv2dFn(Function):
             else:
                 small, big = _require_fp32(dy, "Conv2dFn.backward (5x5 weight gradient)"), (xp if xp is not None else split_planes(x, 2))
             cs = Ci if wg5 == "stem" else Co
-            if tgt is not None and _SIDE["enabled"]:
-                with _on_side_stream(dy.device, (small, big)):
-                    conv_wgrad5_planes(small, big, B, cs, H, W, wg5 == "stem", out=tgt, accumulate=True)
-            elif tgt is not None:
+            if tgt is not None:
                 conv_wgrad5_planes(small, big, B, cs, H, W, wg5 == "stem", out=tgt, accumulate=True)
             else:
                 dw = conv_wgrad5_planes(small, big, B, cs, H, W, wg5 == "stem")
@@ -623,10 +605,7 @@ class Conv2dFn(Function):
             if wg_planes and (ns_d in (0, 2)):
                 if xp is None:
                     xp = split_planes(x, 2)
-                if tgt is not None and _SIDE["enabled"]:
-                    with _on_side_stream(dy.device, (xp, dyp)):
-                        conv_wgrad_planes(xp, dyp, B, Ci, H, W, Co, KS, up2, out=tgt, accumulate=True)
-                elif tgt is not None:
+                if tgt is not None:
                     conv_wgrad_planes(xp, dyp, B, Ci, H, W, Co, KS, up2, out=tgt, accumulate=True)
                 else:
                     dw = conv_wgrad_planes(xp, dyp, B, Ci, H, W, Co, KS, up2)
@@ -634,10 +613,7 @@ class Conv2dFn(Function):
                 if x is None:
                     raise abi.HipExtensionError("Conv2dFn.backward: conv math mode changed between forward and backward")
                 _require_fp32(dy, "Conv2dFn.backward (weight gradient)")
-                if tgt is not None and _SIDE["enabled"]:
-                    with _on_side_stream(dy.device, (x, dy)):
-                        conv_wgrad_raw(x, dy, B, Ci, H, W, Co, KS, up2, out=tgt, accumulate=True)
-                elif tgt is not None:
+                if tgt is not None:
                     conv_wgrad_raw(x, dy, B, Ci, H, W, Co, KS, up2, out=tgt, accumulate=True)
                 else:
                     dw = conv_wgrad_raw(x, dy, B, Ci, H, W, Co, KS, up2)

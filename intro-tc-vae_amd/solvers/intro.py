@@ -10,8 +10,6 @@ from typing import Optional
 import torch
 from torch import Tensor
 
-import os
-
 from hipvae import ddp
 from models import bn_groups
 from ops import noise, reparameterize
@@ -30,8 +28,8 @@ class IntroSolver(VAESolver):
         # dec(z_rec) | dec(z_fake), in both phases -- run as ONE batched pass of 2B images with two BatchNorm groups
         # (models.bn_groups): 13 network passes become 7 launches-wise, every conv GEMM / weight gradient sees twice
         # the pixels, and the results are those of separate passes (per-pass batch statistics, same draw order, same
-        # running-buffer order).  ``batch_passes = False`` (ITCV_BATCH_PASSES=0) issues the 13 passes one by one.
-        self.batch_passes = os.environ.get("ITCV_BATCH_PASSES", "1") != "0"
+        # running-buffer order).  ``batch_passes = False`` issues the 13 passes one by one (the tests compare the two).
+        self.batch_passes = True
 
     def _exp_elbo(self, rec_rows: Tensor, kl_rows: Tensor) -> Tensor:
         """intro.py:102-103  mean_j exp(-2 * scale * (rec_j + kl_j))."""

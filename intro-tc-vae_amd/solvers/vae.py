@@ -10,7 +10,7 @@ import torch
 from torch import Tensor
 
 from hipvae import ddp
-from hipvae.functional import conv_math_scope, direct_grad_accumulation, side_join
+from hipvae.functional import conv_math_scope, direct_grad_accumulation
 from hipvae.flat import FlatGroup, clip_grad_norm, plain_adam_hparams
 from ops import kl_divergence, reconstruction_loss
 from utils import SingletonWriter
@@ -103,7 +103,6 @@ class VAESolver:
             g.zero_grad()
         with direct_grad_accumulation():     # wgrad / BN / bias kernels add straight into the flat buffers
             loss.backward()
-        side_join()                          # weight gradients were issued on the side stream
         if defer_average:
             pending = [ddp.average_async(g.flat_g) for g in groups]
             return lambda: [f() for f in pending]

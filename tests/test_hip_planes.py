@@ -79,6 +79,91 @@ def test_planes_conv_equals_gather_conv(HF, mode, case):
         assert torch.equal(a, b) or rel_err(a, b) < 2e-6   # equal unless the two kernels split K differently
 
 
+# Launches with MORE TILES THAN CUs at W <= 64: the persistent band kernel (conv_fwd_bf16p3_kernel: tile walk, next-tile
+# band prefetch, weight-ring wrap, stores draining under the next tile) in every instantiation the c2 step uses
+# (LOG2W 6/5/4/3 x 64/128-row tiles x up2) -- the kernel bench.py's roofline is quoted on.
+PERSIST_CASES = [  # B, Ci, H, W, Co, up2
+    (20, 64, 64, 64, 64, False), (20, 64, 64, 64, 64, True),            # LOG2W 6, BM 64: 320 tiles
+    (72, 128, 32, 32, 128, False), (36, 64, 32, 32, 128, False),        # LOG2W 5, BM 128 (288 tiles) / BM 64 (2 x 144)
+    (72, 64, 32, 32, 64, True),                                         # LOG2W 5, BM 64, up2
+    (136, 64, 16, 16, 256, True), (272, 64, 16, 16, 64, False),         # LOG2W 4, BM 128 up2 (2 x 136) / BM 64
+    (520, 128, 8, 8, 128, False), (1040, 64, 8, 8, 256, False),         # LOG2W 3, BM 64 (2 x 130) / BM 128 (2 x 260)
+]
+
+
+@pytest.mark.parametrize("case", PERSIST_CASES)
+def test_persistent_band_kernel_vs_one_tile_kernel_and_fp64(HF, case):
+    """Forward and data-gradient (bf16x3, planes): the persistent kernel with its default 256 blocks, with 5 blocks (long
+    tile walks, ragged tile lists) and the one-tile-per-block kernel (band_persist_blocks = 0) are BIT-IDENTICAL, and
+    within 5e-5 of the result scale of an fp64 convolution (checked on the first / last two images; the reference the
+    kernel replaces: ATen conv forward / data-gradient, /root/reference/models.py:28-47)."""
+    B, Ci, H, W, Co, up2 = case
+    g = torch.Generator().manual_seed(sum(case[:5]))
+    hs, ws = (H // 2, W // 2) if up2 else (H, W)
+    x = torch.randn(B, Ci, hs, ws, generator=g)
+    w = torch.randn(Co, Ci, 3, 3, generator=g) / (Ci * 9) ** 0.5
+    dy = torch.randn(B, Co, H, W, generator=g)
+    xd, wd, dyd = x.to(dev()), w.to(dev()), dy.to(dev())
+    sel = [0, 1, B - 2, B - 1]
+
+    def run():
+        with HF.conv_math_scope("bf16x3"):
+            y = HF.conv_apply_planes(HF.split_planes(xd, 2), wd, wd, 0, None, B, Ci, H, W, Co, 3, up2, 2)
+            dx = HF.conv_apply_planes(HF.split_planes(dyd, 2), wd, wd, 1, None, B, Co, H, W, Ci, 3, False, 2)
+        return y, dx
+
+    assert HF.get_option("band_persist_blocks") == 256
+    y, dx = run()
+    for blocks in (0, 5):
+        with HF.option_scope("band_persist_blocks", blocks):
+            y2, dx2 = run()
+        assert torch.equal(y, y2) and torch.equal(dx, dx2), blocks
+    xin = F.interpolate(x[sel].double(), scale_factor=2, mode="nearest") if up2 else x[sel].double()
+    assert rel_err(y[sel], F.conv2d(xin, w.double(), padding=1)) < 5e-5
+    assert rel_err(dx[sel], F.conv_transpose2d(dy[sel].double(), w.double(), padding=1)) < 5e-5
+    # the other inner product (v_mfma_f32_32x32x16_bf16): same values to rounding
+    with HF.option_scope("band_m16", 0):
+        y3, dx3 = run()
+    assert rel_err(y3, y) < 2e-6 and rel_err(dx3, dx) < 2e-6 and not torch.equal(y3, y)
+
+
+def test_option_api_validates(HF):
+    """itcv_set_option: unknown names and out-of-range values are refused; nothing is read from the environment."""
+    from hipvae import abi
+    for name, value in (("band_persist_blocks", -1), ("band_persist_blocks", 4096), ("band_m16", 2), ("no_such_option", 1)):
+        with pytest.raises(RuntimeError):
+            HF.set_option(name, value)
+    assert HF.get_option("no_such_option") == -1
+    assert HF.get_option("band_m16") == 1 and HF.get_option("band_persist_blocks") == 256
+
+
+def test_batched_bn_act_conv_chain_vs_fp64(HF):
+    """The c2 step's heaviest chain at its batched size: 2 x 64 images of 64 channels at 64x64 -- BatchNorm (two groups,
+    train mode) + LeakyReLU emitting PLANES ONLY, then the 64 -> 64 3x3 conv on the persistent band kernel (2048 tiles) --
+    against fp64 BatchNorm over the whole batch and an fp64 conv on the first / last images (models.py:37-47)."""
+    B, C, S = 128, 64, 64
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(B, C, S, S, generator=g) * 1.3 + 0.2
+    gamma, beta = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.1
+    w = torch.randn(C, C, 3, 3, generator=g) / (C * 9) ** 0.5
+    d = dev()
+    rm, rv = torch.zeros(C, device=d), torch.ones(C, device=d)
+    nbt = torch.zeros((), dtype=torch.int64, device=d)
+    with HF.conv_math_scope("bf16x3"):
+        a = HF.BnActFn.apply(x.to(d), gamma.to(d), beta.to(d), None, rm, rv, nbt, 1e-4, 0.1, 0.2, False, True, None, 2, 0,
+                             False, True, 2)
+        assert HF._tagged_planes(a, 2) is not None and not a._itcv_planes[4]      # planes only: the fp32 tensor is not written
+        y = HF.Conv2dFn.apply(a, w.to(d), None, False)
+    assert int(nbt) == 2
+    sel = [0, 1, 63, 64, 126, 127]
+    ref = []
+    for grp in (slice(0, 64), slice(64, 128)):
+        xg = x[grp].double()
+        ref.append(F.leaky_relu(F.batch_norm(xg, None, None, gamma.double(), beta.double(), True, 0.1, 1e-4), 0.2))
+    act = torch.cat(ref)
+    assert rel_err(y[sel], F.conv2d(act[sel], w.double(), padding=1)) < 5e-5
+
+
 WGRAD_CASES = [  # B, Ci, H, W, Co, up2
     (2, 64, 16, 16, 64, False), (4, 128, 4, 4, 256, False), (2, 32, 32, 32, 48, False), (1, 64, 64, 64, 64, False),
     (2, 128, 16, 16, 64, True), (2, 512, 8, 8, 256, False), (8, 24, 8, 8, 136, False),
