@@ -66,7 +66,8 @@ PEAK_F32_MFMA_TFLOPS = 157.3
 PEAK_BF16_MFMA_TFLOPS = 2500.0       # dense; a split product costs 3 (bf16x3) or 6 (bf16x6) bf16 MFMA products
 PMC_FILE = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
 DTYPE = {"fp32": "f32", "bf16x3": "f32 in/out/accumulate, conv products on split-bf16 MFMA (bf16x3)",
-         "bf16x6": "f32 in/out/accumulate, conv products on split-bf16 MFMA (bf16x6, fp32-class)"}
+         "bf16x6": "f32 in/out/accumulate, conv products on split-bf16 MFMA (bf16x6, fp32-class)",
+         "f16x3": "f32 in/out/accumulate, conv products on split-fp16 MFMA (two scaled fp16 planes, 3 products, fp32-class)"}
 
 
 class _DS:
@@ -165,8 +166,9 @@ def roofline_of(records, math, steps, eager_elapsed, where):
     dom_label, dom = max(buckets.items(), key=lambda kv: kv[1][2])
     achieved = dom[1] / dom[2] * 1e-12
     if "bf16s" in dom_label or "bf16p" in dom_label:
-        products = 3 if "NS=2" in dom_label else 6
-        peak, peak_note = PEAK_BF16_MFMA_TFLOPS / products, f"2500 TFLOP/s dense bf16 MFMA / {products} bf16 products per fp32 product"
+        products = 6 if "NS=3" in dom_label else 3
+        kind = "fp16" if "NS=4" in dom_label else "bf16"
+        peak, peak_note = PEAK_BF16_MFMA_TFLOPS / products, f"2500 TFLOP/s dense {kind} MFMA / {products} {kind} products per fp32 product"
     else:
         peak, peak_note = PEAK_F32_MFMA_TFLOPS, "dense fp32 MFMA"
     traffic, traffic_note = None, "no PMC record for this kernel / arithmetic"
@@ -298,7 +300,7 @@ def main():
                     help="N=1, c2: skip the additional fp32 / bf16x6 measurements (the 'modes' object)")
     ap.add_argument("--sync-bn", action="store_true",
                     help="N>1: all-reduce BatchNorm moments (full-batch parity mode); default is per-rank statistics")
-    ap.add_argument("--math", choices=["bf16x3", "bf16x6", "fp32"], default="bf16x3",
+    ap.add_argument("--math", choices=["bf16x3", "bf16x6", "fp32", "f16x3"], default="bf16x3",
                     help="conv GEMM arithmetic: bf16x3 = use_amp=True (the reference's config default), split-bf16 "
                          "MFMA with fp32 accumulate; bf16x6 = fp32-class 3-way split; fp32 = exact fp32 MFMA")
     ap.add_argument("--no-graph", action="store_true", help="time eager launches instead of hipGraph replays (N=1)")

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define ITCV_ABI_VERSION 2
+#define ITCV_ABI_VERSION 3
 
 /* ---- library ------------------------------------------------------------------------- */
 int itcv_abi_version(void);
@@ -96,8 +96,22 @@ int itcv_conv2d_fwd_bf16s(const float* x, const void* wp, const float* bias, flo
  * tensor; itcv_conv2d_fwd_bf16p then moves both operands global -> LDS by LDS-DMA (no gather, no
  * conversion in the conv kernel).  Same contract and shapes (its own workspace query) and -- bit for bit -- results as
  * itcv_conv2d_fwd_bf16s (replaces the same ATen conv forward / data-gradient, models.py:28-47). */
+/* Plane formats (the `ns` argument of every planes entry point):
+ *   2  two bf16 planes  ("bf16x3": 3 products, ~2^-16 per product)
+ *   3  three bf16 planes ("bf16x6": 6 products, fp32 class)
+ *   4  ITCV_PLANES_F16X2: two FP16 planes hi = fp16(S x), lo = fp16(S x - hi) of the tensor times a power-of-two scale S
+ *      ("f16x3": the same 3 products on v_mfma_f32_*_f16 carry 22 significand bits, ~2^-21 per product -- fp32 class at the
+ *      bf16x3 rate).  The record {S, 1/S} (16 bytes) sits behind the second plane; producers write it, consumers multiply
+ *      their result by the exact inverse.  Activations use S = 1 (O(1) values; |x| >= 65504 becomes inf and surfaces as a
+ *      NaN loss); packed weights S = 2^8; gradient tensors a scale derived from a rigorous bound of their magnitude
+ *      (BatchNorm backward: from per-channel maxima it computes anyway; itcv_absmax for loose fp32 tensors). */
+#define ITCV_PLANES_F16X2 4
 size_t itcv_planes_bytes(int B, int C, int HW, int ns);
 int itcv_split_planes(const float* x, void* planes, int B, int C, int HW, int ns, void* stream);
+/* parts[256] = block maxima of |x| (x 16-byte aligned); feeds the `amax` arguments below, which derive the power-of-two
+ * scale of an fp16 split from them on the device (no host round trip).  amax == NULL means S = 1. */
+int itcv_absmax(const float* x, size_t n, float* parts, void* stream);
+int itcv_split_planes_scaled(const float* x, void* planes, int B, int C, int HW, int ns, const float* amax, void* stream);
 size_t itcv_conv2d_fwd_bf16p_workspace(int B, int Ci, int H, int W, int Co, int KS, int ns);
 int itcv_conv2d_fwd_bf16p(const void* xplanes, const void* wp, const float* bias, float* y, int B, int Ci, int H,
                           int W, int Co, int KS, int up2, int ns, void* ws, size_t ws_bytes, void* stream);
@@ -116,7 +130,8 @@ int itcv_conv2d_fwd_bf16p_st(const void* xplanes, const void* wp, const float* b
 int itcv_conv2d_wgrad_bf16p_supported(int B, int Ci, int H, int W, int Co, int KS);
 size_t itcv_conv2d_wgrad_bf16p_workspace(int B, int Ci, int H, int W, int Co, int KS);
 int itcv_conv2d_wgrad_bf16p(const void* xplanes, const void* dyplanes, float* dw, int B, int Ci, int H, int W,
-                            int Co, int KS, int up2, int accumulate, void* ws, size_t ws_bytes, void* stream);
+                            int Co, int KS, int up2, int ns /* 2 or 4 */, int accumulate, void* ws, size_t ws_bytes,
+                            void* stream);
 /* nn.Linear(K -> N) at batch B (models.py:233,270) as skinny exact-fp32 MFMA GEMMs, in every conv-math mode:
  * y[B][N] = x[B][K] w[N][K]^T + bias;  dx[B][K] = dy[B][N] w;  dw[N][K] (+)= dy^T x.  Deterministic
  * split-K; itcv_linear_workspace serves all three. */
@@ -133,7 +148,8 @@ int itcv_linear_wgrad(const float* dy, const float* x, float* dw, int B, int K, 
 int itcv_conv2d_wgrad5_bf16p_supported(int Cs, int Cb, int H, int W);
 size_t itcv_conv2d_wgrad5_bf16p_workspace(int B, int H);
 int itcv_conv2d_wgrad5_bf16p(const float* small, const void* big_planes, float* dw, int B, int Cs, int H, int W,
-                             int stem, int accumulate, void* ws, size_t ws_bytes, void* stream);
+                             int stem, int ns /* 2 or 4 */, const float* small_amax /* itcv_absmax of `small`, or NULL */,
+                             int accumulate, void* ws, size_t ws_bytes, void* stream);
 /* Direct (vector-ALU, exact fp32) convolution for layers with at most 4 output channels -- the 5x5
  * predict conv 64->3 (models.py:290) and the data-gradient of the 5x5 stem (models.py:213), where a
  * 32-row MFMA tile would be >90 % padding.  for_dgrad = 0: w is [Co][C][KS][KS]; for_dgrad = 1: w is the
@@ -143,7 +159,7 @@ int itcv_conv2d_small_cout_supported(int Co, int KS);
  * (output channel, filter column), every operand fragment is one plane chunk loaded straight from global memory. */
 int itcv_conv2d_small_cout_bf16p_supported(int C, int Co, int KS);
 int itcv_conv2d_small_cout_fwd_bf16p(const void* xplanes, const float* w, const float* bias, float* y, int B, int C,
-                                     int H, int W, int Co, int KS, int for_dgrad, void* stream);
+                                     int H, int W, int Co, int KS, int for_dgrad, int ns /* 2 or 4 */, void* stream);
 int itcv_conv2d_small_cout_fwd(const float* x, const float* w, const float* bias, float* y, int B, int C,
                                int H, int W, int Co, int KS, int for_dgrad, void* stream);
 /* ... and for layers with at most 4 REDUCTION channels (the 5x5 stem 3->64 forward, models.py:213, and
@@ -156,7 +172,8 @@ int itcv_conv2d_small_cin_fwd(const float* x, const float* w, const float* bias,
  * the prediction layer models.py:271) as split-bf16 (bf16x3) products on the matrix cores. */
 int itcv_conv2d_small_cin_bf16x3_supported(int C, int Co, int KS, int W);
 int itcv_conv2d_small_cin_fwd_bf16x3(const float* x, const float* w, const float* bias, float* y, int B, int C, int H,
-                                     int W, int Co, int KS, int for_dgrad, void* stream);
+                                     int W, int Co, int KS, int for_dgrad, int ns /* 2 or 4 */,
+                                     const float* x_amax /* itcv_absmax of x, or NULL */, void* stream);
 /* Split-bf16 weight gradient (same arithmetic, same workspace size as itcv_conv2d_wgrad_workspace):
  * needs KS in {1,3}, Ci % 32 == 0, W % 8 == 0, Co > 32 and a materialised (not virtually upsampled) x. */
 int itcv_conv2d_wgrad_bf16s_supported(int Ci, int H, int W, int Co, int KS);

@@ -97,26 +97,92 @@ __device__ __forceinline__ T fold_strided(T init, const T* __restrict__ p, size_
   return s;
 }
 
-// ---- split-bf16 operands: x = sum_p plane_p(x), each plane a bf16; 8 values -> one 16-byte chunk per plane
+// ---- split operands: x = sum_p plane_p(x); 8 values -> one 16-byte chunk per plane -------------------------------
+// bf16 planes (formats 2 and 3): each plane is the bf16 rounding of the remaining residual.
+// fp16 planes (format ITCV_PLANES_F16X2, "f16x3"): hi = fp16(S*x), lo = fp16(S*x - hi) with a power-of-two scale S per
+// tensor: 22 significand bits in two planes, so the same THREE matrix-core products as bf16x3 (hi*lo + lo*hi + hi*hi)
+// reach ~2^-21 per product -- fp32 class -- where two bf16 planes reach 2^-16.  fp16's narrow exponent is what the scale is
+// for: S maps the tensor's magnitude bound just under 2^15, and the fp16 matrix cores keep subnormal inputs (measured on
+// gfx950: tools/f16_probe.hip), so values far below the bound degrade gracefully (absolute error 2^-25 / S) instead of
+// flushing.  The product of two such operands comes out scaled by Sa*Sb; the consumer's epilogue multiplies by the exact
+// inverse.  Every scaled tensor carries its {S, 1/S} next to the data (ScaleRec, "trailer" of a planes buffer).
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
-template <int NS>
-__device__ __forceinline__ void split8(const float (&v)[8], u32x4 (&out)[NS]) {
-  bf16x8 pl[NS];
-#pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    float r = v[j];
-#pragma unroll
-    for (int p = 0; p < NS; ++p) {
-      const __bf16 b = (__bf16)r;
-      pl[p][j] = b;
-      r -= (float)b;
-    }
-  }
-#pragma unroll
-  for (int p = 0; p < NS; ++p) out[p] = __builtin_bit_cast(u32x4, pl[p]);
+struct ScaleRec {   // 16 bytes: lives behind the last plane of an fp16 planes buffer
+  float scale, inv;
+  float pad[2];
+};
+constexpr int kWeightScaleLog2 = 8;   // packed fp16 weights are stored times 2^8 (|w| < 255 representable; typical |w| ~ 0.02 -> 5)
+
+// power-of-two scale that maps `bound` (>= every |value| of the tensor) into [2^14, 2^15); 1 for 0 / inf / nan bounds
+__host__ __device__ inline float scale_for_bound(float bound) {
+  if (!(bound > 0.f) || !(bound < 3.0e38f)) return 1.f;
+  int e;
+  (void)frexpf(bound, &e);          // bound = m * 2^e, m in [0.5, 1)  =>  bound < 2^e
+  int k = 15 - e;                   // bound * 2^k < 2^15
+  k = k > 126 ? 126 : (k < -126 ? -126 : k);
+  return ldexpf(1.f, k);
 }
+
+template <int NS, bool F16 = false>
+__device__ __forceinline__ void split8(const float (&v)[8], u32x4 (&out)[NS], float scale = 1.f) {
+  if constexpr (F16) {
+    static_assert(NS == 2, "fp16 planes come in pairs");
+    f16x8 hi, lo;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float r = v[j] * scale;
+      const _Float16 h = (_Float16)r;
+      hi[j] = h;
+      lo[j] = (_Float16)(r - (float)h);
+    }
+    out[0] = __builtin_bit_cast(u32x4, hi), out[1] = __builtin_bit_cast(u32x4, lo);
+  } else {
+    bf16x8 pl[NS];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float r = v[j];
+#pragma unroll
+      for (int p = 0; p < NS; ++p) {
+        const __bf16 b = (__bf16)r;
+        pl[p][j] = b;
+        r -= (float)b;
+      }
+    }
+#pragma unroll
+    for (int p = 0; p < NS; ++p) out[p] = __builtin_bit_cast(u32x4, pl[p]);
+  }
+}
+
+// matrix-core products on 16-byte fragments (8 x 16-bit) of either element type
+typedef float mm_f32x4 __attribute__((ext_vector_type(4)));
+typedef float mm_f32x16 __attribute__((ext_vector_type(16)));
+template <bool F16>
+__device__ __forceinline__ mm_f32x4 mma16x16x32(bf16x8 a, bf16x8 b, mm_f32x4 c) {
+  if constexpr (F16)
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  else
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+template <bool F16>
+__device__ __forceinline__ mm_f32x16 mma32x32x16(bf16x8 a, bf16x8 b, mm_f32x16 c) {
+  if constexpr (F16)
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  else
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+
+// max of n non-negative floats at p, by one wave (all 64 lanes call; result in every lane)
+__device__ __forceinline__ float wave_absmax_of(const float* __restrict__ p, int n) {
+  float m = 0.f;
+  for (int i = threadIdx.x & 63; i < n; i += 64) m = fmaxf(m, p[i]);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  return m;
+}
+constexpr int kAbsmaxParts = 256;   // block maxima written by itcv_absmax (one float each)
 
 // ---- optional per-launch timing of the GEMM-class kernels (bench.py's roofline leg) ------------
 // When enabled, a HIP event pair is recorded on the launch stream immediately around the MAIN kernel

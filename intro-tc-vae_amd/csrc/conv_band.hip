@@ -17,8 +17,9 @@ static __device__ u32x4 g_zero_chunk = {0u, 0u, 0u, 0u};
 //   * 8 MFMA waves (two per SIMD, so one fills the other's barrier / LDS-latency bubbles) + 4 loader waves.
 // Ingest per MFMA drops ~2.8x.  Same arithmetic and K order as the other split-bf16 kernels (bit-identical).
 
-template <int LOG2W, int BM, bool UP2, bool M16 = false>
+template <int LOG2W, int BM, bool UP2, bool M16 = false, bool F16 = false>
 __global__ __launch_bounds__(768) void conv_fwd_bf16p2_kernel(ConvArgsP2 a) {
+  static_assert(!F16 || M16, "the fp16 planes form uses the 16x16x32 products");
   constexpr int W = 1 << LOG2W, WP = W + 2, BN = 256, KC = 4, NS = 2;
   constexpr int WM = BM / 64, WN = 8 / WM, WTN = BN / WN, TM = 2, TN = WTN / 32;   // 128: 2x4 waves of 64x64; 64: 1x8 of 64x32
   constexpr int ASZ = NS * KC * BM;                // chunks per weight tile
@@ -138,9 +139,10 @@ __global__ __launch_bounds__(768) void conv_fwd_bf16p2_kernel(ConvArgsP2 a) {
   }
 
   // -------------------------------------------------------------------- MFMA waves
-  typedef BandMfma<M16> MM;
+  typedef BandMfma<M16, F16> MM;
   typedef typename MM::acc_t acc_t;
   constexpr int TS = MM::TS, KSN = MM::KSN, TMx = 32 * TM / TS, TNx = WTN / TS;   // MFMA tiles of a wave's 64 x WTN block
+  const float oscale = F16 ? a.xscale->inv * (1.f / (float)(1 << kWeightScaleLog2)) : 1.f;   // exact: powers of two
   const int wm = wid / WN, wn = wid % WN, lr = lane & (TS - 1), kq = lane / TS;
   // band index of this lane's pixel of N-tile j (centre tap)
   uint32_t hoff[TNx];
@@ -281,6 +283,7 @@ __global__ __launch_bounds__(768) void conv_fwd_bf16p2_kernel(ConvArgsP2 a) {
           const int m = m0 + wm * 64 + i * TS + MM::row(r, kq);
           if (m < a.Co) {
             float v = acc[i][j][r];
+            if (F16) v *= oscale;
             if (a.bias) v += a.bias[m];
             out[base + (size_t)m * HW] = v;
           }
@@ -348,8 +351,9 @@ __global__ __launch_bounds__(768) void conv_fwd_bf16p2_kernel(ConvArgsP2 a) {
 // barrier / LDS-latency bubbles.  Removed.)
 // ROWS2 (128- and 256-wide images): the 128-pixel tile is 2 rows x 64 columns instead of (half of) one row -- the band is
 // 4 x 66 chunks per plane row instead of 3 x 130, a third less ingest per tile.
-template <int LOG2W, int BM, bool UP2, int BN, bool M16 = false, bool ROWS2 = false>
+template <int LOG2W, int BM, bool UP2, int BN, bool M16 = false, bool ROWS2 = false, bool F16 = false>
 __global__ __launch_bounds__(768) void conv_fwd_bf16p3_kernel(ConvArgsP2 a) {
+  static_assert(!F16 || M16, "the fp16 planes form uses the 16x16x32 products");
   constexpr int NMW = 8;
   // BN = 256 pixels per tile for W <= 64 (whole rows); BN = 128 for 128- and 256-wide images: one row, or one half of a
   // row whose band then takes its halo columns from the neighbouring half instead of the zero padding
@@ -526,9 +530,10 @@ __global__ __launch_bounds__(768) void conv_fwd_bf16p3_kernel(ConvArgsP2 a) {
   }
 
   // -------------------------------------------------------------------- MFMA waves
-  typedef BandMfma<M16> MM;
+  typedef BandMfma<M16, F16> MM;
   typedef typename MM::acc_t acc_t;
   constexpr int TS = MM::TS, KSN = MM::KSN, TMx = 32 * TM / TS, TNx = WTN / TS;   // MFMA tiles of a wave's 32*TM x WTN block
+  const float oscale = F16 ? a.xscale->inv * (1.f / (float)(1 << kWeightScaleLog2)) : 1.f;   // exact: powers of two
   const int wm = wid / WN, wn = wid % WN, lr = lane & (TS - 1), kq = lane / TS;
   uint32_t hoff[TNx];
 #pragma unroll
@@ -660,6 +665,7 @@ __global__ __launch_bounds__(768) void conv_fwd_bf16p3_kernel(ConvArgsP2 a) {
           const int m = m0 + wm * 32 * TM + i * TS + MM::row(r, kq);
           if (m < a.Co) {
             float v = acc[i][j][r];
+            if (F16) v *= oscale;
             if (a.bias) v += a.bias[m];
             out[base + (size_t)m * HW] = v;
           }
@@ -720,92 +726,87 @@ FwdPlanP2 plan_fwd_p2(int B, int Ci, int H, int W, int Co, int KS, int ns) {
 
 static int band_persistent_blocks() { return g_opt.band_persist_blocks; }   // itcv_set_option("band_persist_blocks")
 
-template <int LOG2W, int BM, bool UP2>
-static void launch_fwd_p2_cfg(const ConvArgsP2& a, int splits, size_t lds, hipStream_t st) {
-  auto kern = conv_fwd_bf16p2_kernel<LOG2W, BM, UP2>;
-  static size_t attr = 0;
-  if (attr < lds) {
+template <typename K>
+static void set_lds(K kern, size_t& have, size_t lds) {
+  if (have < lds) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr = lds;
-  }
-  const int ids = cdiv(a.nt, 8) * 8 * a.mt;
-  if (!a.stats && ids > band_persistent_blocks() && band_persistent_blocks() > 0) {
-    // more tiles than CUs: persistent blocks (one per CU) that prefetch the next tile's band under the current MFMAs
-    if (band_m16()) {
-      auto pk = conv_fwd_bf16p3_kernel<LOG2W, BM, UP2, 256, true>;
-      static size_t pattr16 = 0;
-      if (pattr16 < lds) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pk), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        pattr16 = lds;
-      }
-      launch_timed(pk, dim3(band_persistent_blocks(), splits), dim3(768), lds, st, a);
-      return;
-    }
-    auto pk = conv_fwd_bf16p3_kernel<LOG2W, BM, UP2, 256>;
-    static size_t pattr = 0;
-    if (pattr < lds) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pk), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      pattr = lds;
-    }
-    launch_timed(pk, dim3(band_persistent_blocks(), splits), dim3(768), lds, st, a);
-    return;
-  }
-  dim3 grid(ids, splits);
-  if (band_m16() && !a.stats) {
-    auto k16 = conv_fwd_bf16p2_kernel<LOG2W, BM, UP2, true>;
-    static size_t attr16 = 0;
-    if (attr16 < lds) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k16), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      attr16 = lds;
-    }
-    launch_timed(k16, grid, dim3(768), lds, st, a);
-    return;
-  }
-  launch_timed(kern, grid, dim3(768), lds, st, a);
-}
-template <int LOG2W>
-static void launch_fwd_p2_w(const ConvArgsP2& a, int bm, int up2, int splits, size_t lds, hipStream_t st) {
-  if (bm == 64) {
-    if (up2) launch_fwd_p2_cfg<LOG2W, 64, true>(a, splits, lds, st);
-    else launch_fwd_p2_cfg<LOG2W, 64, false>(a, splits, lds, st);
-  } else {
-    if (up2) launch_fwd_p2_cfg<LOG2W, 128, true>(a, splits, lds, st);
-    else launch_fwd_p2_cfg<LOG2W, 128, false>(a, splits, lds, st);
+    have = lds;
   }
 }
 
-// 128- / 256-wide images: the persistent kernel with 128-pixel tiles
-template <int LOG2W, int BM, bool UP2, bool M16, bool ROWS2>
-static void launch_fwd_p3_wide_k(const ConvArgsP2& a, int splits, size_t lds, hipStream_t st) {
-  auto pk = conv_fwd_bf16p3_kernel<LOG2W, BM, UP2, 128, M16, ROWS2>;
-  static size_t pattr = 0;
-  if (pattr < lds) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pk), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    pattr = lds;
+// W <= 64: 256-pixel tiles.  More tiles than CUs (and no tile statistics wanted): persistent blocks (one per CU) that
+// prefetch the next tile's band under the current MFMAs; else one tile per block.
+template <int LOG2W, int BM, bool UP2, bool F16>
+static void launch_fwd_p2_cfg(const ConvArgsP2& a, int splits, size_t lds, hipStream_t st) {
+  const int ids = cdiv(a.nt, 8) * 8 * a.mt, pb = band_persistent_blocks();
+  const bool persistent = !a.stats && pb > 0 && ids > pb;
+  const bool m16 = F16 || (band_m16() && !a.stats);    // launches that produce tile statistics keep the 32x32x16 form
+  if (persistent) {
+    if (m16) {
+      auto pk = conv_fwd_bf16p3_kernel<LOG2W, BM, UP2, 256, true, false, F16>;
+      static size_t have = 0;
+      set_lds(pk, have, lds);
+      launch_timed(pk, dim3(pb, splits), dim3(768), lds, st, a);
+    } else if constexpr (!F16) {
+      auto pk = conv_fwd_bf16p3_kernel<LOG2W, BM, UP2, 256, false, false, false>;
+      static size_t have = 0;
+      set_lds(pk, have, lds);
+      launch_timed(pk, dim3(pb, splits), dim3(768), lds, st, a);
+    }
+    return;
   }
+  const dim3 grid(ids, splits);
+  if (m16) {
+    auto k16 = conv_fwd_bf16p2_kernel<LOG2W, BM, UP2, true, F16>;
+    static size_t have = 0;
+    set_lds(k16, have, lds);
+    launch_timed(k16, grid, dim3(768), lds, st, a);
+  } else if constexpr (!F16) {
+    auto kern = conv_fwd_bf16p2_kernel<LOG2W, BM, UP2, false, false>;
+    static size_t have = 0;
+    set_lds(kern, have, lds);
+    launch_timed(kern, grid, dim3(768), lds, st, a);
+  }
+}
+template <int LOG2W, bool F16>
+static void launch_fwd_p2_w(const ConvArgsP2& a, int bm, int up2, int splits, size_t lds, hipStream_t st) {
+  if (bm == 64) {
+    if (up2) launch_fwd_p2_cfg<LOG2W, 64, true, F16>(a, splits, lds, st);
+    else launch_fwd_p2_cfg<LOG2W, 64, false, F16>(a, splits, lds, st);
+  } else {
+    if (up2) launch_fwd_p2_cfg<LOG2W, 128, true, F16>(a, splits, lds, st);
+    else launch_fwd_p2_cfg<LOG2W, 128, false, F16>(a, splits, lds, st);
+  }
+}
+
+// 128- / 256-wide images: the persistent kernel with 128-pixel tiles (2 rows x 64 columns)
+template <int LOG2W, int BM, bool UP2, bool M16, bool ROWS2, bool F16>
+static void launch_fwd_p3_wide_k(const ConvArgsP2& a, int splits, size_t lds, hipStream_t st) {
+  auto pk = conv_fwd_bf16p3_kernel<LOG2W, BM, UP2, 128, M16, ROWS2, F16>;
+  static size_t have = 0;
+  set_lds(pk, have, lds);
   const int ids = cdiv(a.nt, 8) * 8 * a.mt, nb = band_persistent_blocks() > 0 ? band_persistent_blocks() : 256;
   launch_timed(pk, dim3(ids < nb ? ids : nb, splits), dim3(768), lds, st, a);
 }
-template <int LOG2W, int BM, bool UP2>
+template <int LOG2W, int BM, bool UP2, bool F16>
 static void launch_fwd_p3_wide_cfg(const ConvArgsP2& a, int splits, size_t lds, int rows2, hipStream_t st) {
-  if constexpr (LOG2W >= 7) {
-    if (rows2) {
-      if (band_m16()) launch_fwd_p3_wide_k<LOG2W, BM, UP2, true, true>(a, splits, lds, st);
-      else launch_fwd_p3_wide_k<LOG2W, BM, UP2, false, true>(a, splits, lds, st);
-      return;
-    }
+  const bool m16 = F16 || band_m16();
+  if (rows2) {
+    if (m16) launch_fwd_p3_wide_k<LOG2W, BM, UP2, true, true, F16>(a, splits, lds, st);
+    else if constexpr (!F16) launch_fwd_p3_wide_k<LOG2W, BM, UP2, false, true, false>(a, splits, lds, st);
+    return;
   }
-  if (band_m16()) launch_fwd_p3_wide_k<LOG2W, BM, UP2, true, false>(a, splits, lds, st);
-  else launch_fwd_p3_wide_k<LOG2W, BM, UP2, false, false>(a, splits, lds, st);
+  if (m16) launch_fwd_p3_wide_k<LOG2W, BM, UP2, true, false, F16>(a, splits, lds, st);
+  else if constexpr (!F16) launch_fwd_p3_wide_k<LOG2W, BM, UP2, false, false, false>(a, splits, lds, st);
 }
-template <int LOG2W>
+template <int LOG2W, bool F16>
 static void launch_fwd_p3_wide(const ConvArgsP2& a, int bm, int up2, int splits, size_t lds, int rows2, hipStream_t st) {
   if (bm == 64) {
-    if (up2) launch_fwd_p3_wide_cfg<LOG2W, 64, true>(a, splits, lds, rows2, st);
-    else launch_fwd_p3_wide_cfg<LOG2W, 64, false>(a, splits, lds, rows2, st);
+    if (up2) launch_fwd_p3_wide_cfg<LOG2W, 64, true, F16>(a, splits, lds, rows2, st);
+    else launch_fwd_p3_wide_cfg<LOG2W, 64, false, F16>(a, splits, lds, rows2, st);
   } else {
-    if (up2) launch_fwd_p3_wide_cfg<LOG2W, 128, true>(a, splits, lds, rows2, st);
-    else launch_fwd_p3_wide_cfg<LOG2W, 128, false>(a, splits, lds, rows2, st);
+    if (up2) launch_fwd_p3_wide_cfg<LOG2W, 128, true, F16>(a, splits, lds, rows2, st);
+    else launch_fwd_p3_wide_cfg<LOG2W, 128, false, F16>(a, splits, lds, rows2, st);
   }
 }
 
@@ -814,18 +815,23 @@ bool band_is_persistent(const ConvArgsP2& a, const FwdPlanP2& p) {
   return p.bn == 128 || (!a.stats && band_persistent_blocks() > 0 && ids > band_persistent_blocks());
 }
 
-void launch_fwd_p2(const ConvArgsP2& a, const FwdPlanP2& p, int W, int up2, hipStream_t st) {
+template <bool F16>
+static void launch_fwd_p2_t(const ConvArgsP2& a, const FwdPlanP2& p, int W, int up2, hipStream_t st) {
   if (p.bn == 128) {
-    if (log2_exact(W) == 7) launch_fwd_p3_wide<7>(a, p.bm, up2, p.splits, p.lds, p.rows2, st);
-    else launch_fwd_p3_wide<8>(a, p.bm, up2, p.splits, p.lds, p.rows2, st);
+    if (log2_exact(W) == 7) launch_fwd_p3_wide<7, F16>(a, p.bm, up2, p.splits, p.lds, p.rows2, st);
+    else launch_fwd_p3_wide<8, F16>(a, p.bm, up2, p.splits, p.lds, p.rows2, st);
     return;
   }
   switch (log2_exact(W)) {
-    case 3: launch_fwd_p2_w<3>(a, p.bm, up2, p.splits, p.lds, st); break;
-    case 4: launch_fwd_p2_w<4>(a, p.bm, up2, p.splits, p.lds, st); break;
-    case 5: launch_fwd_p2_w<5>(a, p.bm, up2, p.splits, p.lds, st); break;
-    default: launch_fwd_p2_w<6>(a, p.bm, up2, p.splits, p.lds, st); break;
+    case 3: launch_fwd_p2_w<3, F16>(a, p.bm, up2, p.splits, p.lds, st); break;
+    case 4: launch_fwd_p2_w<4, F16>(a, p.bm, up2, p.splits, p.lds, st); break;
+    case 5: launch_fwd_p2_w<5, F16>(a, p.bm, up2, p.splits, p.lds, st); break;
+    default: launch_fwd_p2_w<6, F16>(a, p.bm, up2, p.splits, p.lds, st); break;
   }
+}
+void launch_fwd_p2(const ConvArgsP2& a, const FwdPlanP2& p, int W, int up2, int f16, hipStream_t st) {
+  if (f16) launch_fwd_p2_t<true>(a, p, W, up2, st);
+  else launch_fwd_p2_t<false>(a, p, W, up2, st);
 }
 
 }  // namespace itcv

@@ -604,14 +604,16 @@ struct ConvArgsP {
   int ktiles, ktiles_per_split;
   size_t slab_stride;
   size_t plane_stride;   // chunks per plane = B * (Ci/8) * Hs * Ws
+  const ScaleRec* xscale;   // fp16 planes: the input's scale record
 #ifdef ITCV_DIAG
   int ablate;            // diagnostic only (ITCV_ABLATE): 1 no B pieces, 4 no A pieces, 8 no MFMA
 #endif
 };
 
-template <int KS, int BM, int BN, int WM, int WN, bool UP2, int NS, int NSTAGE, bool M16 = false>
+template <int KS, int BM, int BN, int WM, int WN, bool UP2, int NS, int NSTAGE, bool M16 = false, bool F16 = false>
 __global__ __launch_bounds__(512) void conv_fwd_bf16p_kernel(ConvArgsP a) {
   static_assert(!M16 || NS == 2, "the 16x16x32 form is written for two planes");
+  static_assert(!F16 || M16, "the fp16 planes form uses the 16x16x32 products");
   constexpr int BK = 32, KC = BK / 8, P = KS / 2, KKc = KS * KS;
   constexpr int WTM = BM / WM, WTN = BN / WN;
   static_assert(WM * WN == 4 && (BN == 128 || BN == 256) && (BM == 64 || BM == 128), "tile / wave layout");
@@ -698,9 +700,10 @@ __global__ __launch_bounds__(512) void conv_fwd_bf16p_kernel(ConvArgsP a) {
   }
 
   // -------------------------------------------------------------------- MFMA waves
-  typedef BandMfma<M16> MM;
+  typedef BandMfma<M16, F16> MM;
   typedef typename MM::acc_t acc_t;
   constexpr int TS = MM::TS, TMx = WTM / TS, TNx = WTN / TS;
+  const float oscale = F16 ? a.xscale->inv * (1.f / (float)(1 << kWeightScaleLog2)) : 1.f;   // exact: powers of two
   const int wm = wid / WN, wn = wid % WN, lr = lane & (TS - 1), kq = lane / TS;
   acc_t acc[TMx][TNx];
 #pragma unroll
@@ -816,6 +819,7 @@ __global__ __launch_bounds__(512) void conv_fwd_bf16p_kernel(ConvArgsP a) {
         const int m = m0 + wm * WTM + i * TS + MM::row(r, kq);
         if (m < a.Co) {
           float v = acc[i][j][r];
+          if (F16) v *= oscale;
           if (a.bias) v += a.bias[m];
           out[base + (size_t)m * HW] = v;
         }
@@ -824,10 +828,21 @@ __global__ __launch_bounds__(512) void conv_fwd_bf16p_kernel(ConvArgsP a) {
   }
 }
 
-// fp32 NCHW -> planes[p][b][c/8][hw] (C % 8 == 0); one thread per chunk, coalesced over hw
-template <int NS>
-__global__ void split_planes_kernel(const float* __restrict__ x, u32x4* __restrict__ planes, int B, int C8, int HW) {
+// fp32 NCHW -> planes[p][b][c/8][hw] (C % 8 == 0); one thread per chunk, coalesced over hw.
+// F16: fp16 hi/lo planes of S*x; S comes from `amax` (kAbsmaxParts block maxima of |x|, itcv_absmax) or is 1 when amax is
+// null (activations: O(1) values, see common.h); the record {S, 1/S} is written behind the second plane.
+template <int NS, bool F16 = false>
+__global__ void split_planes_kernel(const float* __restrict__ x, u32x4* __restrict__ planes, int B, int C8, int HW,
+                                    const float* __restrict__ amax) {
   const size_t total = (size_t)B * C8 * HW;
+  float scale = 1.f;
+  if constexpr (F16) {
+    if (amax) scale = scale_for_bound(wave_absmax_of(amax, kAbsmaxParts));
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+      ScaleRec* rec = reinterpret_cast<ScaleRec*>(planes + (size_t)NS * total);
+      rec->scale = scale, rec->inv = 1.f / scale, rec->pad[0] = rec->pad[1] = 0.f;
+    }
+  }
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
     const size_t bc = i / HW;
     const int hw = (int)(i - bc * HW);
@@ -836,10 +851,29 @@ __global__ void split_planes_kernel(const float* __restrict__ x, u32x4* __restri
 #pragma unroll
     for (int j = 0; j < 8; ++j) v[j] = src[(size_t)j * HW];
     u32x4 pl[NS];
-    split8<NS>(v, pl);
+    split8<NS, F16>(v, pl, scale);
 #pragma unroll
     for (int p = 0; p < NS; ++p) planes[(size_t)p * total + i] = pl[p];
   }
+}
+
+// out[blockIdx.x] = max |x| over the block's grid-stride share (kAbsmaxParts blocks; NaNs are ignored by fmaxf: they
+// travel through the conversion itself)
+__global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x, size_t n, float* __restrict__ out) {
+  __shared__ float red[4];
+  float m = 0.f;
+  const size_t n4 = n / 4;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+    const float4 v = reinterpret_cast<const float4*>(x)[i];
+    m = fmaxf(fmaxf(m, fabsf(v.x)), fmaxf(fmaxf(fabsf(v.y), fabsf(v.z)), fabsf(v.w)));
+  }
+  if (blockIdx.x == 0)
+    for (size_t i = n4 * 4 + threadIdx.x; i < n; i += 256) m = fmaxf(m, fabsf(x[i]));
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) out[blockIdx.x] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
 }
 
 // wp[kt = cib*KK + tap][plane][kc][Mp] 16-byte chunks of 8 bf16: channels cib*32 + kc*8 + j
@@ -847,7 +881,7 @@ __global__ void split_planes_kernel(const float* __restrict__ x, u32x4* __restri
 // its contiguous direction -- forward: the (c, tap) run of row m; data-gradient: the (m, tap) run of channel c -- into
 // LDS, then every thread emits whole 16-byte chunks (8 channels of one (tap, m)) with m fastest across the lanes.
 // Tiles of a layer: (Mp / 32) * cpt, tile = mt32 * cpt + cib.
-template <int NS, int KK>
+template <int NS, int KK, bool F16 = false>
 __device__ __forceinline__ void pack_weight_bf16s_body(const float* __restrict__ w, u32x4* __restrict__ wp, int Ci,
                                                        int for_dgrad, int C, int M, int cpt, int Mp, int tile) {
   constexpr int RUN = 32 * KK, PITCH = RUN + 1;      // odd pitch: the column reads below are conflict free
@@ -887,18 +921,18 @@ __device__ __forceinline__ void pack_weight_bf16s_body(const float* __restrict__
       v[j] = for_dgrad ? sw[cl * PITCH + ml * KK + (KK - 1 - tap)] : sw[ml * PITCH + cl * KK + tap];
     }
     u32x4 pl[NS];
-    split8<NS>(v, pl);
+    split8<NS, F16>(v, pl, F16 ? (float)(1 << kWeightScaleLog2) : 1.f);
     const int kt = cib * KK + tap;
 #pragma unroll
     for (int p = 0; p < NS; ++p) wp[(((size_t)kt * NS + p) * 4 + kc) * Mp + m0 + ml] = pl[p];
   }
 }
 
-template <int NS>
+template <int NS, bool F16 = false>
 __global__ __launch_bounds__(256) void pack_weight_bf16s_kernel(const float* __restrict__ w, u32x4* __restrict__ wp, int Co,
                                                                 int Ci, int KK, int for_dgrad, int C, int M, int cpt, int Mp) {
-  if (KK == 9) pack_weight_bf16s_body<NS, 9>(w, wp, Ci, for_dgrad, C, M, cpt, Mp, blockIdx.x);
-  else pack_weight_bf16s_body<NS, 1>(w, wp, Ci, for_dgrad, C, M, cpt, Mp, blockIdx.x);
+  if (KK == 9) pack_weight_bf16s_body<NS, 9, F16>(w, wp, Ci, for_dgrad, C, M, cpt, Mp, blockIdx.x);
+  else pack_weight_bf16s_body<NS, 1, F16>(w, wp, Ci, for_dgrad, C, M, cpt, Mp, blockIdx.x);
 }
 
 // Many layers in one launch: a device-resident table of descriptors, every layer owns a contiguous block range.
@@ -911,7 +945,7 @@ struct PackDesc {
 };
 static_assert(sizeof(PackDesc) == 56, "PackDesc layout is part of the ABI (itcv_pack_desc_bytes)");
 
-template <int NS>
+template <int NS, bool F16 = false>
 __global__ __launch_bounds__(256) void pack_weights_bf16s_table_kernel(const PackDesc* __restrict__ tab, int n) {
   // the block's layer = the last descriptor whose first block is <= blockIdx.x: all descriptors are looked at in
   // parallel (a serial walk costs one memory round trip per layer)
@@ -926,9 +960,9 @@ __global__ __launch_bounds__(256) void pack_weights_bf16s_table_kernel(const Pac
   __syncthreads();
   const PackDesc d = tab[e];
   if (d.KK == 9)
-    pack_weight_bf16s_body<NS, 9>(d.w, d.wp, d.Ci, d.for_dgrad, d.C, d.M, d.cpt, d.Mp, blockIdx.x - d.block0);
+    pack_weight_bf16s_body<NS, 9, F16>(d.w, d.wp, d.Ci, d.for_dgrad, d.C, d.M, d.cpt, d.Mp, blockIdx.x - d.block0);
   else
-    pack_weight_bf16s_body<NS, 1>(d.w, d.wp, d.Ci, d.for_dgrad, d.C, d.M, d.cpt, d.Mp, blockIdx.x - d.block0);
+    pack_weight_bf16s_body<NS, 1, F16>(d.w, d.wp, d.Ci, d.for_dgrad, d.C, d.M, d.cpt, d.Mp, blockIdx.x - d.block0);
 }
 
 // ------------------------------------------------------------------------------ wgrad
@@ -1286,6 +1320,8 @@ struct WgradArgsP {
   int wseg_shift;           // images wider than 64 (LOG2W = 6 instantiation): log2(W / 64) 64-pixel segments per row
   int groups;               // tiles_m * tiles_n * splits: (tile, K slice) pairs, three blocks (filter rows) each
   size_t xplane, dyplane;   // chunks per plane
+  const ScaleRec* xscale;   // fp16 planes: scale records of x and dy (the slabs are multiplied by 1 / (Sx * Sdy))
+  const ScaleRec* dyscale;
 #ifdef ITCV_DIAG
   int debug;                // diagnostic only (ITCV_ABLATE & 64): block 0 reports main-loop shader cycles / steps in slab[0..1]
 #endif
@@ -1302,7 +1338,7 @@ __device__ __forceinline__ void tr_read8(bf16x8& dst, uint32_t addr0, uint32_t a
 
 // KH = 2 (the 64 x 64 tile): the eight MFMA waves are two groups of four that take alternate halves of a step's four
 // 16-pixel k-steps and keep separate slabs (slab index split*KH + kh) -- the tile is too small for eight waves otherwise.
-template <int LOG2W, bool UP2, int BM, int BN, int NST, int NLW, int KH = 1>
+template <int LOG2W, bool UP2, int BM, int BN, int NST, int NLW, int KH = 1, bool F16 = false>
 __global__ __launch_bounds__(512 + 64 * NLW) void conv_wgrad_bf16p_kernel(WgradArgsP a) {
   constexpr int W = 1 << LOG2W, NR = 64 >> LOG2W, WP = W + 2, NP = NR * WP;   // band: NR rows x (W+2) columns
   constexpr int PXA = 68, PXB = ((NP + 11) / 16) * 16 + 4;                     // row strides = 4 (mod 16) chunks: conflict-free tr reads
@@ -1460,9 +1496,9 @@ __global__ __launch_bounds__(512 + 64 * NLW) void conv_wgrad_bf16p_kernel(WgradA
 #pragma unroll
           for (int tp = 0; tp < 3; ++tp) {
             f32x16 c = acc[tp][0];
-            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[cur][0], bfr[cur][tp][1], c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[cur][1], bfr[cur][tp][0], c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[cur][0], bfr[cur][tp][0], c, 0, 0, 0);
+            c = mma32x32x16<F16>(af[cur][0], bfr[cur][tp][1], c);
+            c = mma32x32x16<F16>(af[cur][1], bfr[cur][tp][0], c);
+            c = mma32x32x16<F16>(af[cur][0], bfr[cur][tp][0], c);
             acc[tp][0] = c;
           }
           if (kk == 0) __builtin_amdgcn_sched_group_barrier(0x100, 16, 0);   // the first k-step's own reads
@@ -1498,9 +1534,9 @@ __global__ __launch_bounds__(512 + 64 * NLW) void conv_wgrad_bf16p_kernel(WgradA
               tr_read8(bfr[pl], bd + hidx16[kk * 2], bd + hidx16[kk * 2 + 1]);
             }
             f32x16 c = acc[tp][j];
-            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bfr[1], c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], bfr[0], c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bfr[0], c, 0, 0, 0);
+            c = mma32x32x16<F16>(af[0], bfr[1], c);
+            c = mma32x32x16<F16>(af[1], bfr[0], c);
+            c = mma32x32x16<F16>(af[0], bfr[0], c);
             acc[tp][j] = c;
           }
       }
@@ -1515,6 +1551,7 @@ __global__ __launch_bounds__(512 + 64 * NLW) void conv_wgrad_bf16p_kernel(WgradA
     }
   }
   // slab[split][tap][co][ci]
+  const float oscale = F16 ? a.xscale->inv * a.dyscale->inv : 1.f;   // exact: powers of two
 #pragma unroll
   for (int j = 0; j < TNw; ++j) {
     const int ci = ci0 + 32 * (wn * TNw + j) + l31;
@@ -1525,7 +1562,7 @@ __global__ __launch_bounds__(512 + 64 * NLW) void conv_wgrad_bf16p_kernel(WgradA
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int co = co0 + 32 * wm + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        if (co < a.Co) out[(size_t)co * a.Ci] = acc[tp][j][r];
+        if (co < a.Co) out[(size_t)co * a.Ci] = F16 ? acc[tp][j][r] * oscale : acc[tp][j][r];
       }
     }
   }
@@ -1539,10 +1576,13 @@ __global__ __launch_bounds__(512 + 64 * NLW) void conv_wgrad_bf16p_kernel(WgradA
 // pixel) are staged K-major in LDS and read back through ds_read_b64_tr_b16; S fragments are 8 consecutive pixels of
 // a (shifted) row, split in registers.  A wave owns a few image rows (T row staged once, used by the five S rows it
 // pairs with) and all 5 x 64 (dh, cb) accumulators; its partial result goes to a slab, folded by wgrad5_reduce.
-template <int SG>
+// F16: T is given as fp16 planes (scale record behind them); S is split in registers into fp16 planes of Ss*S with Ss from
+// `sm_amax` (block maxima of |S|, itcv_absmax; null: Ss = 1 -- the stem's S is the input image).
+template <int SG, bool F16 = false>
 __global__ __launch_bounds__(256) void conv_wgrad5_planes_kernel(const float* __restrict__ sm, const u32x4* __restrict__ tp,
                                                                 float* __restrict__ slab, int B, int CS, int H, int W,
-                                                                int rows_per_job, int njobs, size_t plane_stride) {
+                                                                int rows_per_job, int njobs, size_t plane_stride,
+                                                                const float* __restrict__ sm_amax) {
   constexpr int PXS = 68;                          // row stride of the staged T row: 4 (mod 16) chunks, see conv_wgrad_bf16p_kernel
   constexpr int RSZ = 2 * 8 * PXS;                 // chunks per staged row ([plane][c8][px], up to 64 px)
   __shared__ u32x4 rows[4][RSZ];
@@ -1557,6 +1597,11 @@ __global__ __launch_bounds__(256) void conv_wgrad5_planes_kernel(const float* __
   const bool row_used = cs < CS;
   const int i16 = lane & 15, q = i16 >> 2, pp = i16 & 3;   // transposed-read lane roles
   const uint32_t rbase = lds_addr(rows[wv]);
+  float sscale = 1.f, oscale = 1.f;
+  if constexpr (F16) {
+    if (sm_amax) sscale = scale_for_bound(wave_absmax_of(sm_amax, kAbsmaxParts));
+    oscale = reinterpret_cast<const ScaleRec*>(tp + 2 * plane_stride)->inv / sscale;      // exact: powers of two
+  }
   f32x4_t acc[5][4];
 #pragma unroll
   for (int dh = 0; dh < 5; ++dh)
@@ -1600,14 +1645,14 @@ __global__ __launch_bounds__(256) void conv_wgrad5_planes_kernel(const float* __
           v[j] = (hok && (unsigned)ww < (unsigned)W) ? sp[ww] : 0.f;
         }
         u32x4 ap[2];
-        split8<2>(v, ap);
+        split8<2, F16>(v, ap, sscale);
         const bf16x8 a0 = __builtin_bit_cast(bf16x8, ap[0]), a1 = __builtin_bit_cast(bf16x8, ap[1]);
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) {
           f32x4_t c = acc[dh][nt];
-          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, bfr[nt][1], c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, bfr[nt][0], c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, bfr[nt][0], c, 0, 0, 0);
+          c = mma16x16x32<F16>(a0, bfr[nt][1], c);
+          c = mma16x16x32<F16>(a1, bfr[nt][0], c);
+          c = mma16x16x32<F16>(a0, bfr[nt][0], c);
           acc[dh][nt] = c;
         }
       }
@@ -1621,7 +1666,7 @@ __global__ __launch_bounds__(256) void conv_wgrad5_planes_kernel(const float* __
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
-      for (int i = 0; i < 4; ++i) out[((4 * kg + i) * 5 + dh) * 64 + nt * 16 + n] = acc[dh][nt][i];
+      for (int i = 0; i < 4; ++i) out[((4 * kg + i) * 5 + dh) * 64 + nt * 16 + n] = F16 ? acc[dh][nt][i] * oscale : acc[dh][nt][i];
 }
 
 // dw (+)= sum_jobs slab: element e = (m = cs*5 + dw, dh, cb); stem: dW[cb][cs][dh][dw], predict: dW[cs][cb][dh][dw]
@@ -1906,14 +1951,14 @@ static void launch_fwd_b(const ConvArgsB& a, int bm, int splits, int up2, hipStr
   }
 }
 
-template <int KS, int BM, int BN, int WM, int WN, bool UP2, int NS, int NSTAGE>
+template <int KS, int BM, int BN, int WM, int WN, bool UP2, int NS, int NSTAGE, bool F16>
 static void launch_fwd_p_cfg(const ConvArgsP& a, int splits, hipStream_t st) {
   constexpr size_t lds = (size_t)NSTAGE * NS * 4 * (BM + BN) * 16;
   static_assert(lds <= 160 * 1024, "LDS ring too large");
   dim3 grid(cdiv(a.nt, 8) * 8 * a.mt, splits), blk(512);
   if constexpr (NS == 2) {
-    if (band_m16()) {
-      auto k16 = conv_fwd_bf16p_kernel<KS, BM, BN, WM, WN, UP2, NS, NSTAGE, true>;
+    if (F16 || band_m16()) {
+      auto k16 = conv_fwd_bf16p_kernel<KS, BM, BN, WM, WN, UP2, NS, NSTAGE, true, F16>;
       static bool attr16 = false;
       if (!attr16) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k16), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1923,27 +1968,29 @@ static void launch_fwd_p_cfg(const ConvArgsP& a, int splits, hipStream_t st) {
       return;
     }
   }
-  auto kern = conv_fwd_bf16p_kernel<KS, BM, BN, WM, WN, UP2, NS, NSTAGE>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
+  if constexpr (!F16) {
+    auto kern = conv_fwd_bf16p_kernel<KS, BM, BN, WM, WN, UP2, NS, NSTAGE>;
+    static bool attr_set = false;
+    if (!attr_set) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      attr_set = true;
+    }
+    launch_timed(kern, grid, blk, lds, st, a);
   }
-  launch_timed(kern, grid, blk, lds, st, a);
 }
-template <int KS, int NS, int NSTAGE>
+template <int KS, int NS, int NSTAGE, bool F16>
 static void launch_fwd_p_st(const ConvArgsP& a, int bm, int splits, int up2, hipStream_t st) {
   if (bm == 64) {
-    if (up2) launch_fwd_p_cfg<KS, 64, 256, 1, 4, true, NS, NSTAGE>(a, splits, st);
-    else launch_fwd_p_cfg<KS, 64, 256, 1, 4, false, NS, NSTAGE>(a, splits, st);
+    if (up2) launch_fwd_p_cfg<KS, 64, 256, 1, 4, true, NS, NSTAGE, F16>(a, splits, st);
+    else launch_fwd_p_cfg<KS, 64, 256, 1, 4, false, NS, NSTAGE, F16>(a, splits, st);
   } else {
-    if (up2) launch_fwd_p_cfg<KS, 128, 128, 2, 2, true, NS, NSTAGE>(a, splits, st);
-    else launch_fwd_p_cfg<KS, 128, 128, 2, 2, false, NS, NSTAGE>(a, splits, st);
+    if (up2) launch_fwd_p_cfg<KS, 128, 128, 2, 2, true, NS, NSTAGE, F16>(a, splits, st);
+    else launch_fwd_p_cfg<KS, 128, 128, 2, 2, false, NS, NSTAGE, F16>(a, splits, st);
   }
 }
-template <int KS, int NS>
+template <int KS, int NS, bool F16 = false>
 static void launch_fwd_p(const ConvArgsP& a, int bm, int splits, int up2, hipStream_t st) {
-  launch_fwd_p_st<KS, NS, NS == 2 ? 3 : 2>(a, bm, splits, up2, st);   // ring depth: three stages where LDS allows (two planes)
+  launch_fwd_p_st<KS, NS, NS == 2 ? 3 : 2, F16>(a, bm, splits, up2, st);   // ring depth: three stages where LDS allows (two planes)
 }
 
 struct WgPlanP {
@@ -1974,7 +2021,7 @@ static WgPlanP plan_wgrad_p(int B, int Ci, int H, int W, int Co) {
   return p;
 }
 
-template <int LOG2W, bool UP2, int BM, int BN, int KH = 1>
+template <int LOG2W, bool UP2, int BM, int BN, int KH, bool F16>
 static void launch_wgrad_p_cfg(const WgradArgsP& a, int blocks, hipStream_t st) {
   constexpr int W = 1 << LOG2W, NP = (64 >> LOG2W) * (W + 2), PXB = ((NP + 11) / 16) * 16 + 4;
   constexpr size_t stage_bytes = (size_t)(2 * (BM / 8) * 68 + 2 * (BN / 8) * PXB) * 16;
@@ -1982,7 +2029,7 @@ static void launch_wgrad_p_cfg(const WgradArgsP& a, int blocks, hipStream_t st) 
   constexpr size_t lds = NST * stage_bytes;
   if constexpr (lds <= 160 * 1024) {
     constexpr int NLW = 4;   // loader waves (eight were measured no faster, and spill in the 128 x 128 form)
-    auto kern = conv_wgrad_bf16p_kernel<LOG2W, UP2, BM, BN, NST, NLW, KH>;
+    auto kern = conv_wgrad_bf16p_kernel<LOG2W, UP2, BM, BN, NST, NLW, KH, F16>;
     static bool attr_set = false;
     if (!attr_set) {
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1991,21 +2038,26 @@ static void launch_wgrad_p_cfg(const WgradArgsP& a, int blocks, hipStream_t st) 
     launch_timed(kern, dim3(blocks), dim3(512 + 64 * NLW), lds, st, a);
   }
 }
-template <int LOG2W>
-static void launch_wgrad_p(const WgradArgsP& a, int bm, int bn, int up2, int blocks, hipStream_t st) {
+template <int LOG2W, bool F16>
+static void launch_wgrad_p_t(const WgradArgsP& a, int bm, int bn, int up2, int blocks, hipStream_t st) {
   if (bm == 64 && bn == 64) {
-    if (up2) launch_wgrad_p_cfg<LOG2W, true, 64, 64, 2>(a, blocks, st);
-    else launch_wgrad_p_cfg<LOG2W, false, 64, 64, 2>(a, blocks, st);
+    if (up2) launch_wgrad_p_cfg<LOG2W, true, 64, 64, 2, F16>(a, blocks, st);
+    else launch_wgrad_p_cfg<LOG2W, false, 64, 64, 2, F16>(a, blocks, st);
   } else if (bm == 64) {
-    if (up2) launch_wgrad_p_cfg<LOG2W, true, 64, 128>(a, blocks, st);
-    else launch_wgrad_p_cfg<LOG2W, false, 64, 128>(a, blocks, st);
+    if (up2) launch_wgrad_p_cfg<LOG2W, true, 64, 128, 1, F16>(a, blocks, st);
+    else launch_wgrad_p_cfg<LOG2W, false, 64, 128, 1, F16>(a, blocks, st);
   } else if (bn == 128) {
-    if (up2) launch_wgrad_p_cfg<LOG2W, true, 128, 128>(a, blocks, st);
-    else launch_wgrad_p_cfg<LOG2W, false, 128, 128>(a, blocks, st);
+    if (up2) launch_wgrad_p_cfg<LOG2W, true, 128, 128, 1, F16>(a, blocks, st);
+    else launch_wgrad_p_cfg<LOG2W, false, 128, 128, 1, F16>(a, blocks, st);
   } else {
-    if (up2) launch_wgrad_p_cfg<LOG2W, true, 128, 64>(a, blocks, st);
-    else launch_wgrad_p_cfg<LOG2W, false, 128, 64>(a, blocks, st);
+    if (up2) launch_wgrad_p_cfg<LOG2W, true, 128, 64, 1, F16>(a, blocks, st);
+    else launch_wgrad_p_cfg<LOG2W, false, 128, 64, 1, F16>(a, blocks, st);
   }
+}
+template <int LOG2W>
+static void launch_wgrad_p(const WgradArgsP& a, int bm, int bn, int up2, int blocks, int f16, hipStream_t st) {
+  if (f16) launch_wgrad_p_t<LOG2W, true>(a, bm, bn, up2, blocks, st);
+  else launch_wgrad_p_t<LOG2W, false>(a, bm, bn, up2, blocks, st);
 }
 
 template <int KS, int CB, int NS>
@@ -2121,20 +2173,25 @@ int itcv_conv2d_bf16s_supported(int Ci, int Co, int KS) {
   return (KS == 1 || KS == 3) && Ci >= 32 && Ci % 32 == 0 && Co >= 33;
 }
 
+static inline int planes_of_fmt(int ns) { return ns == ITCV_PLANES_F16X2 ? 2 : ns; }   // planes per tensor of a format code
+static inline bool fmt_ok(int ns) { return ns == 2 || ns == 3 || ns == ITCV_PLANES_F16X2; }
+
 size_t itcv_conv2d_packed_weight_bytes_bf16s(int Co, int Ci, int KS, int for_dgrad, int ns) {
   const int M = for_dgrad ? Ci : Co, C = for_dgrad ? Co : Ci;
   const int bm = M <= 64 ? 64 : 128;
-  return (size_t)KS * KS * (pad32(C) / 32) * ns * 4 * (cdiv(M, bm) * bm) * 16;
+  return (size_t)KS * KS * (pad32(C) / 32) * planes_of_fmt(ns) * 4 * (cdiv(M, bm) * bm) * 16;
 }
 
 int itcv_conv2d_pack_weight_bf16s(const float* w, void* wp, int Co, int Ci, int KS, int for_dgrad, int ns,
                                   void* stream) {
-  ITCV_REQUIRE(w && wp && Co > 0 && Ci > 0 && (KS == 1 || KS == 3) && (ns == 2 || ns == 3),
-               "itcv_conv2d_pack_weight_bf16s");
+  ITCV_REQUIRE(w && wp && Co > 0 && Ci > 0 && (KS == 1 || KS == 3) && fmt_ok(ns), "itcv_conv2d_pack_weight_bf16s");
   const int M = for_dgrad ? Ci : Co, C = for_dgrad ? Co : Ci;
   const int bm = M <= 64 ? 64 : 128, Mp = cdiv(M, bm) * bm, cpt = pad32(C) / 32;
   const int blocks = (Mp / 32) * cpt;   // one block per 32 x 32-channel tile
-  if (ns == 2)
+  if (ns == ITCV_PLANES_F16X2)
+    hipLaunchKernelGGL((pack_weight_bf16s_kernel<2, true>), dim3(blocks), dim3(256), 0, S(stream), w, static_cast<u32x4*>(wp),
+                       Co, Ci, KS * KS, for_dgrad, C, M, cpt, Mp);
+  else if (ns == 2)
     hipLaunchKernelGGL(pack_weight_bf16s_kernel<2>, dim3(blocks), dim3(256), 0, S(stream), w, static_cast<u32x4*>(wp),
                        Co, Ci, KS * KS, for_dgrad, C, M, cpt, Mp);
   else
@@ -2148,8 +2205,8 @@ size_t itcv_pack_desc_bytes(void) { return sizeof(PackDesc); }
 
 int itcv_conv2d_pack_desc_bf16s(void* host_desc, const float* w, void* wp, int Co, int Ci, int KS, int for_dgrad,
                                 int ns, int block0) {
-  if (!(host_desc && w && wp && Co > 0 && Ci > 0 && (KS == 1 || KS == 3) && (ns == 2 || ns == 3) && block0 >= 0)) {
-    fail("%s: bad argument (pointers, Co/Ci > 0, KS in {1,3}, ns in {2,3}, block0 >= 0)", "itcv_conv2d_pack_desc_bf16s");
+  if (!(host_desc && w && wp && Co > 0 && Ci > 0 && (KS == 1 || KS == 3) && fmt_ok(ns) && block0 >= 0)) {
+    fail("%s: bad argument (pointers, Co/Ci > 0, KS in {1,3}, ns in {2,3,4}, block0 >= 0)", "itcv_conv2d_pack_desc_bf16s");
     return -1;     // the success value is a block count
   }
   const int M = for_dgrad ? Ci : Co, C = for_dgrad ? Co : Ci;
@@ -2165,9 +2222,11 @@ int itcv_conv2d_pack_desc_bf16s(void* host_desc, const float* w, void* wp, int C
 }
 
 int itcv_conv2d_pack_weights_bf16s(const void* dev_table, int n, int total_blocks, int ns, void* stream) {
-  ITCV_REQUIRE(dev_table && n > 0 && total_blocks > 0 && (ns == 2 || ns == 3), "itcv_conv2d_pack_weights_bf16s");
+  ITCV_REQUIRE(dev_table && n > 0 && total_blocks > 0 && fmt_ok(ns), "itcv_conv2d_pack_weights_bf16s");
   const PackDesc* tab = static_cast<const PackDesc*>(dev_table);
-  if (ns == 2)
+  if (ns == ITCV_PLANES_F16X2)
+    hipLaunchKernelGGL((pack_weights_bf16s_table_kernel<2, true>), dim3(total_blocks), dim3(256), 0, S(stream), tab, n);
+  else if (ns == 2)
     hipLaunchKernelGGL(pack_weights_bf16s_table_kernel<2>, dim3(total_blocks), dim3(256), 0, S(stream), tab, n);
   else
     hipLaunchKernelGGL(pack_weights_bf16s_table_kernel<3>, dim3(total_blocks), dim3(256), 0, S(stream), tab, n);
@@ -2183,7 +2242,7 @@ size_t itcv_conv2d_fwd_bf16s_workspace(int B, int Ci, int H, int W, int Co, int 
 
 size_t itcv_conv2d_fwd_bf16p_workspace(int B, int Ci, int H, int W, int Co, int KS, int ns) {
   if (B <= 0 || Ci <= 0 || H <= 0 || W <= 0 || Co <= 0) return 0;
-  const FwdPlanP2 p2 = plan_fwd_p2(B, Ci, H, W, Co, KS, ns);
+  const FwdPlanP2 p2 = plan_fwd_p2(B, Ci, H, W, Co, KS, planes_of_fmt(ns));
   if (p2.ok) return p2.splits > 1 ? (size_t)p2.splits * B * Co * H * W * sizeof(float) : 0;
   return itcv_conv2d_fwd_bf16s_workspace(B, Ci, H, W, Co, KS);
 }
@@ -2236,22 +2295,35 @@ int itcv_conv2d_fwd_bf16s(const float* x, const void* wp, const float* bias, flo
 }
 
 size_t itcv_planes_bytes(int B, int C, int HW, int ns) {
-  if (B <= 0 || C <= 0 || HW <= 0 || (C & 7) || ns < 2 || ns > 3) return 0;
-  return (size_t)ns * B * (C / 8) * HW * 16;
+  if (B <= 0 || C <= 0 || HW <= 0 || (C & 7) || !fmt_ok(ns)) return 0;
+  // fp16 planes carry their scale record {S, 1/S} behind the last plane
+  return (size_t)planes_of_fmt(ns) * B * (C / 8) * HW * 16 + (ns == ITCV_PLANES_F16X2 ? sizeof(ScaleRec) : 0);
 }
 
-int itcv_split_planes(const float* x, void* planes, int B, int C, int HW, int ns, void* stream) {
-  ITCV_REQUIRE(x && planes && B > 0 && C > 0 && HW > 0 && (C & 7) == 0 && (ns == 2 || ns == 3), "itcv_split_planes");
+int itcv_absmax(const float* x, size_t n, float* parts, void* stream) {
+  ITCV_REQUIRE(x && parts && n > 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0, "itcv_absmax");
+  hipLaunchKernelGGL(absmax_kernel, dim3(kAbsmaxParts), dim3(256), 0, S(stream), x, n, parts);
+  ITCV_CHECK_LAUNCH("itcv_absmax");
+  return 0;
+}
+
+int itcv_split_planes_scaled(const float* x, void* planes, int B, int C, int HW, int ns, const float* amax, void* stream) {
+  ITCV_REQUIRE(x && planes && B > 0 && C > 0 && HW > 0 && (C & 7) == 0 && fmt_ok(ns), "itcv_split_planes");
+  ITCV_REQUIRE(!amax || ns == ITCV_PLANES_F16X2, "itcv_split_planes(a scale only applies to fp16 planes)");
   const size_t total = (size_t)B * (C / 8) * HW;
   const int blocks = (int)(cdivz(total, 256) < 8192 ? cdivz(total, 256) : 8192);
-  if (ns == 2)
-    hipLaunchKernelGGL(split_planes_kernel<2>, dim3(blocks), dim3(256), 0, S(stream), x, static_cast<u32x4*>(planes), B,
-                       C / 8, HW);
+  u32x4* pl = static_cast<u32x4*>(planes);
+  if (ns == ITCV_PLANES_F16X2)
+    hipLaunchKernelGGL((split_planes_kernel<2, true>), dim3(blocks), dim3(256), 0, S(stream), x, pl, B, C / 8, HW, amax);
+  else if (ns == 2)
+    hipLaunchKernelGGL(split_planes_kernel<2>, dim3(blocks), dim3(256), 0, S(stream), x, pl, B, C / 8, HW, amax);
   else
-    hipLaunchKernelGGL(split_planes_kernel<3>, dim3(blocks), dim3(256), 0, S(stream), x, static_cast<u32x4*>(planes), B,
-                       C / 8, HW);
+    hipLaunchKernelGGL(split_planes_kernel<3>, dim3(blocks), dim3(256), 0, S(stream), x, pl, B, C / 8, HW, amax);
   ITCV_CHECK_LAUNCH("itcv_split_planes");
   return 0;
+}
+int itcv_split_planes(const float* x, void* planes, int B, int C, int HW, int ns, void* stream) {
+  return itcv_split_planes_scaled(x, planes, B, C, HW, ns, nullptr, stream);
 }
 
 // Same contract as itcv_conv2d_fwd_bf16s, with the input given as pre-split planes
@@ -2265,6 +2337,7 @@ int itcv_conv2d_fwd_bf16p(const void* xplanes, const void* wp, const float* bias
 // this shape cannot -- split-K slabs, or a tile form without the staged epilogue).
 int itcv_conv2d_fwd_bf16p_stat_tiles(int B, int Ci, int H, int W, int Co, int KS, int ns) {
   if (B <= 0 || Ci <= 0 || H <= 0 || W <= 0 || Co <= 0 || !itcv_conv2d_bf16s_supported(Ci, Co, KS)) return 0;
+  if (ns == ITCV_PLANES_F16X2) return 0;     // the staged epilogue exists for the bf16 32x32x16 form only
   const FwdPlanP2 p2 = plan_fwd_p2(B, Ci, H, W, Co, KS, ns);
   return (p2.ok && p2.splits == 1 && p2.bn == 256) ? p2.nt : 0;
 }
@@ -2273,10 +2346,14 @@ int itcv_conv2d_fwd_bf16p_st(const void* xplanes, const void* wp, const float* b
                              int W, int Co, int KS, int up2, int ns, float* tile_stats, void* ws, size_t ws_bytes,
                              void* stream) {
   if (int e = check_dims("itcv_conv2d_fwd_bf16p", B, Ci, H, W, Co, KS)) return e;
-  if (tile_stats && !itcv_conv2d_fwd_bf16p_stat_tiles(B, Ci, H, W, Co, KS, ns))
-    return fail("%s: tile statistics are not available for this shape (see itcv_conv2d_fwd_bf16p_stat_tiles)",
+  ITCV_REQUIRE(xplanes && wp && y && fmt_ok(ns), "itcv_conv2d_fwd_bf16p");
+  const int f16 = ns == ITCV_PLANES_F16X2;
+  ns = planes_of_fmt(ns);
+  if (tile_stats && (f16 || !itcv_conv2d_fwd_bf16p_stat_tiles(B, Ci, H, W, Co, KS, ns)))
+    return fail("%s: tile statistics are not available for this shape / format (see itcv_conv2d_fwd_bf16p_stat_tiles)",
                 "itcv_conv2d_fwd_bf16p_st");
-  ITCV_REQUIRE(xplanes && wp && y && (ns == 2 || ns == 3), "itcv_conv2d_fwd_bf16p");
+  const size_t in_plane = (size_t)B * (Ci / 8) * (up2 ? (H / 2) * (W / 2) : H * W);
+  const ScaleRec* xrec = f16 ? reinterpret_cast<const ScaleRec*>(static_cast<const u32x4*>(xplanes) + 2 * in_plane) : nullptr;
   if (!itcv_conv2d_bf16s_supported(Ci, Co, KS))
     return fail("%s: shape not supported by the split-bf16 kernel (Ci %% 32, Co > 32, KS 1/3)", "itcv_conv2d_fwd_bf16p");
   if (up2) ITCV_REQUIRE(H % 2 == 0 && W % 2 == 0, "itcv_conv2d_fwd_bf16p(up2)");
@@ -2298,6 +2375,7 @@ int itcv_conv2d_fwd_bf16p_st(const void* xplanes, const void* wp, const float* b
     a.SR = p2.SR, a.NSEG = p2.NSEG, a.NP = p2.NP, a.NPC = p2.NPC, a.PXB = p2.PXB;
     a.h_shift = log2_exact(H);
     a.stats = tile_stats, a.stat_T = p2.nt;
+    a.xscale = xrec;
     a.slab_stride = p2.splits > 1 ? out_elems : 0;
     a.plane_stride = (size_t)B * (Ci / 8) * (up2 ? (H / 2) * (W / 2) : H * W);
 #ifdef ITCV_DIAG
@@ -2305,9 +2383,9 @@ int itcv_conv2d_fwd_bf16p_st(const void* xplanes, const void* wp, const float* b
 #endif
     hipStream_t st = S(stream);
     {
-      ProfScope prof(st, band_is_persistent(a, p2) ? 9 : 8, log2_exact(W), p2.bm, up2 ? 1 : 0, ns,
+      ProfScope prof(st, band_is_persistent(a, p2) ? 9 : 8, log2_exact(W), p2.bm, up2 ? 1 : 0, f16 ? ITCV_PLANES_F16X2 : ns,
                      2.0 * B * H * W * (double)Co * Ci * KS * KS);
-      launch_fwd_p2(a, p2, W, up2, st);
+      launch_fwd_p2(a, p2, W, up2, f16, st);
     }
     ITCV_CHECK_LAUNCH("itcv_conv2d_fwd_bf16p(band)");
     if (p2.splits > 1) {
@@ -2332,18 +2410,21 @@ int itcv_conv2d_fwd_bf16p_st(const void* xplanes, const void* wp, const float* b
   a.N = B * H * W;
   a.mt = p.mt, a.nt = p.nt, a.ktiles = p.ktiles, a.ktiles_per_split = p.kps;
   a.slab_stride = p.splits > 1 ? out_elems : 0;
-  a.plane_stride = (size_t)B * (Ci / 8) * (up2 ? (H / 2) * (W / 2) : H * W);
+  a.plane_stride = in_plane;
+  a.xscale = xrec;
 #ifdef ITCV_DIAG
   a.ablate = diag_ablate();
 #endif
   hipStream_t st = S(stream);
   {
-    ProfScope prof(st, 6, KS, p.bm, up2 ? 1 : 0, ns, 2.0 * B * H * W * (double)Co * Ci * KS * KS);
+    ProfScope prof(st, 6, KS, p.bm, up2 ? 1 : 0, f16 ? ITCV_PLANES_F16X2 : ns, 2.0 * B * H * W * (double)Co * Ci * KS * KS);
     if (KS == 1) {
-      if (ns == 2) launch_fwd_p<1, 2>(a, p.bm, p.splits, up2, st);
+      if (f16) launch_fwd_p<1, 2, true>(a, p.bm, p.splits, up2, st);
+      else if (ns == 2) launch_fwd_p<1, 2>(a, p.bm, p.splits, up2, st);
       else launch_fwd_p<1, 3>(a, p.bm, p.splits, up2, st);
     } else {
-      if (ns == 2) launch_fwd_p<3, 2>(a, p.bm, p.splits, up2, st);
+      if (f16) launch_fwd_p<3, 2, true>(a, p.bm, p.splits, up2, st);
+      else if (ns == 2) launch_fwd_p<3, 2>(a, p.bm, p.splits, up2, st);
       else launch_fwd_p<3, 3>(a, p.bm, p.splits, up2, st);
     }
   }
@@ -2497,9 +2578,10 @@ size_t itcv_conv2d_wgrad_bf16p_workspace(int B, int Ci, int H, int W, int Co, in
 // dw[Co][Ci][3][3] (+)= conv weight gradient from the pre-split planes of x ([2][B][Ci/8][Hs][Ws]; Hs,Ws =
 // H/2,W/2 with up2) and dy ([2][B][Co/8][H][W]); bf16x3 arithmetic (two planes).
 int itcv_conv2d_wgrad_bf16p(const void* xplanes, const void* dyplanes, float* dw, int B, int Ci, int H, int W, int Co,
-                            int KS, int up2, int accumulate, void* ws, size_t ws_bytes, void* stream) {
+                            int KS, int up2, int ns, int accumulate, void* ws, size_t ws_bytes, void* stream) {
   if (int e = check_dims("itcv_conv2d_wgrad_bf16p", B, Ci, H, W, Co, KS)) return e;
-  ITCV_REQUIRE(xplanes && dyplanes && dw, "itcv_conv2d_wgrad_bf16p");
+  ITCV_REQUIRE(xplanes && dyplanes && dw && (ns == 2 || ns == ITCV_PLANES_F16X2), "itcv_conv2d_wgrad_bf16p");
+  const int f16 = ns == ITCV_PLANES_F16X2;
   if (!itcv_conv2d_wgrad_bf16p_supported(B, Ci, H, W, Co, KS))
     return fail("%s: shape not supported (KS 3, W a power of two in 4..256, H a power of two, C %% 8)", "itcv_conv2d_wgrad_bf16p");
   if (up2) ITCV_REQUIRE(H % 2 == 0 && W % 2 == 0, "itcv_conv2d_wgrad_bf16p(up2)");
@@ -2516,6 +2598,8 @@ int itcv_conv2d_wgrad_bf16p(const void* xplanes, const void* dyplanes, float* dw
   a.wseg_shift = W > 64 ? log2_exact(W) - 6 : 0;
   a.xplane = (size_t)B * (Ci / 8) * (up2 ? (H / 2) * (W / 2) : H * W);
   a.dyplane = (size_t)B * (Co / 8) * H * W;
+  a.xscale = f16 ? reinterpret_cast<const ScaleRec*>(a.xp + 2 * a.xplane) : nullptr;
+  a.dyscale = f16 ? reinterpret_cast<const ScaleRec*>(a.dyp + 2 * a.dyplane) : nullptr;
 #ifdef ITCV_DIAG
   a.debug = (diag_ablate() & 64) ? 1 : 0;
 #endif
@@ -2523,13 +2607,13 @@ int itcv_conv2d_wgrad_bf16p(const void* xplanes, const void* dyplanes, float* dw
   a.groups = p.tiles_m * p.tiles_n * p.splits;
   const int blocks = cdiv(a.groups, 8) * 24;
   {
-    ProfScope prof(st, 7, log2_exact(W), p.bm, up2 ? 1 : 0, 2, 2.0 * B * H * W * (double)Co * Ci * KS * KS);
+    ProfScope prof(st, 7, log2_exact(W), p.bm, up2 ? 1 : 0, ns, 2.0 * B * H * W * (double)Co * Ci * KS * KS);
     switch (log2_exact(W)) {
-      case 2: launch_wgrad_p<2>(a, p.bm, p.bn, up2, blocks, st); break;
-      case 3: launch_wgrad_p<3>(a, p.bm, p.bn, up2, blocks, st); break;
-      case 4: launch_wgrad_p<4>(a, p.bm, p.bn, up2, blocks, st); break;
-      case 5: launch_wgrad_p<5>(a, p.bm, p.bn, up2, blocks, st); break;
-      default: launch_wgrad_p<6>(a, p.bm, p.bn, up2, blocks, st); break;
+      case 2: launch_wgrad_p<2>(a, p.bm, p.bn, up2, blocks, f16, st); break;
+      case 3: launch_wgrad_p<3>(a, p.bm, p.bn, up2, blocks, f16, st); break;
+      case 4: launch_wgrad_p<4>(a, p.bm, p.bn, up2, blocks, f16, st); break;
+      case 5: launch_wgrad_p<5>(a, p.bm, p.bn, up2, blocks, f16, st); break;
+      default: launch_wgrad_p<6>(a, p.bm, p.bn, up2, blocks, f16, st); break;
     }
   }
   ITCV_CHECK_LAUNCH("itcv_conv2d_wgrad_bf16p");
@@ -2642,8 +2726,11 @@ size_t itcv_conv2d_wgrad5_bf16p_workspace(int B, int H) {
   return (size_t)B * cdiv(H, rpj) * 16 * 5 * 64 * sizeof(float);
 }
 int itcv_conv2d_wgrad5_bf16p(const float* small, const void* big_planes, float* dw, int B, int Cs, int H, int W,
-                             int stem, int accumulate, void* ws, size_t ws_bytes, void* stream) {
-  ITCV_REQUIRE(small && big_planes && dw && B > 0, "itcv_conv2d_wgrad5_bf16p");
+                             int stem, int ns, const float* small_amax, int accumulate, void* ws, size_t ws_bytes,
+                             void* stream) {
+  ITCV_REQUIRE(small && big_planes && dw && B > 0 && (ns == 2 || ns == ITCV_PLANES_F16X2), "itcv_conv2d_wgrad5_bf16p");
+  ITCV_REQUIRE(!small_amax || ns == ITCV_PLANES_F16X2, "itcv_conv2d_wgrad5_bf16p(a scale only applies to fp16 planes)");
+  const int f16 = ns == ITCV_PLANES_F16X2;
   if (!itcv_conv2d_wgrad5_bf16p_supported(Cs, 64, H, W))
     return fail("%s: needs Cs <= 3, 64 channels on the other side, W in {32, 64}", "itcv_conv2d_wgrad5_bf16p");
   const int rpj = wgrad5_rows_per_job(B, H), njobs = B * cdiv(H, rpj);
@@ -2652,13 +2739,18 @@ int itcv_conv2d_wgrad5_bf16p(const float* small, const void* big_planes, float* 
   hipStream_t st = S(stream);
   const size_t plane_stride = (size_t)B * 8 * H * W;
   {
-    ProfScope prof(st, 2, 5, 64, 0, 2, 2.0 * B * H * W * 64.0 * Cs * 25);
-    if (stem)
-      launch_timed(conv_wgrad5_planes_kernel<1>, dim3(cdiv(njobs, 4)), dim3(256), 0, st, small,
-                   static_cast<const u32x4*>(big_planes), static_cast<float*>(ws), B, Cs, H, W, rpj, njobs, plane_stride);
+    ProfScope prof(st, 2, 5, 64, 0, ns, 2.0 * B * H * W * 64.0 * Cs * 25);
+    const dim3 grid(cdiv(njobs, 4)), blk(256);
+    const u32x4* bp = static_cast<const u32x4*>(big_planes);
+    float* slab = static_cast<float*>(ws);
+    if (stem && f16)
+      launch_timed((conv_wgrad5_planes_kernel<1, true>), grid, blk, 0, st, small, bp, slab, B, Cs, H, W, rpj, njobs, plane_stride, small_amax);
+    else if (stem)
+      launch_timed((conv_wgrad5_planes_kernel<1, false>), grid, blk, 0, st, small, bp, slab, B, Cs, H, W, rpj, njobs, plane_stride, small_amax);
+    else if (f16)
+      launch_timed((conv_wgrad5_planes_kernel<-1, true>), grid, blk, 0, st, small, bp, slab, B, Cs, H, W, rpj, njobs, plane_stride, small_amax);
     else
-      launch_timed(conv_wgrad5_planes_kernel<-1>, dim3(cdiv(njobs, 4)), dim3(256), 0, st, small,
-                   static_cast<const u32x4*>(big_planes), static_cast<float*>(ws), B, Cs, H, W, rpj, njobs, plane_stride);
+      launch_timed((conv_wgrad5_planes_kernel<-1, false>), grid, blk, 0, st, small, bp, slab, B, Cs, H, W, rpj, njobs, plane_stride, small_amax);
   }
   ITCV_CHECK_LAUNCH("itcv_conv2d_wgrad5_bf16p");
   const int total = Cs * 25 * 64;

@@ -70,6 +70,7 @@ struct ConvArgsP2 {
   int h_shift;
   float* stats;                  // optional [2][Co][stat_T]: per-tile sum / sum of squares of the output (BatchNorm statistics)
   int stat_T;
+  const ScaleRec* xscale;        // fp16 planes: the input's scale record (results are multiplied by xscale->inv * 2^-kWeightScaleLog2)
   size_t slab_stride, plane_stride;
 #ifdef ITCV_DIAG
   int debug;   // diagnostic only (ITCV_ABLATE & 64): block 0 / 100 report main-loop shader cycles and 100 MHz ticks in y[0..3]
@@ -85,24 +86,20 @@ __host__ __device__ constexpr int band_taps_per_stage(int bm, int bn, int /*lw*/
 // higher one on v_mfma_f32_16x16x32_bf16 than on 32x32x16 at equal cycles per FLOP (MI355X_MICROARCH.md, DVFS give-back
 // item 7); with 16x16x32 a lane's fragment is still one 16-byte plane chunk (8 channels of a row / pixel), the four
 // lane groups take the four chunks of a 32-channel group, and one MFMA covers the whole group.
-template <bool M16>
+template <bool M16, bool F16 = false>
 struct BandMfma;
-template <>
-struct BandMfma<false> {
+template <bool F16>
+struct BandMfma<false, F16> {
   typedef f32x16 acc_t;
   static constexpr int TS = 32, NR = 16, KSN = 2;        // tile side, accumulator registers, MFMAs (k-steps) per 32-channel group
-  static __device__ __forceinline__ acc_t mma(bf16x8 a, bf16x8 b, acc_t c) {
-    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
-  }
+  static __device__ __forceinline__ acc_t mma(bf16x8 a, bf16x8 b, acc_t c) { return mma32x32x16<F16>(a, b, c); }
   static __device__ __forceinline__ int row(int r, int kq) { return (r & 3) + 8 * (r >> 2) + 4 * kq; }
 };
-template <>
-struct BandMfma<true> {
+template <bool F16>
+struct BandMfma<true, F16> {
   typedef float acc_t __attribute__((ext_vector_type(4)));
   static constexpr int TS = 16, NR = 4, KSN = 1;
-  static __device__ __forceinline__ acc_t mma(bf16x8 a, bf16x8 b, acc_t c) {
-    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
-  }
+  static __device__ __forceinline__ acc_t mma(bf16x8 a, bf16x8 b, acc_t c) { return mma16x16x32<F16>(a, b, c); }
   static __device__ __forceinline__ int row(int r, int kq) { return 4 * kq + r; }
 };
 
@@ -128,7 +125,7 @@ struct FwdPlanP2 {
 
 // conv_band.hip
 FwdPlanP2 plan_fwd_p2(int B, int Ci, int H, int W, int Co, int KS, int ns);
-void launch_fwd_p2(const ConvArgsP2& a, const FwdPlanP2& p, int W, int up2, hipStream_t st);
+void launch_fwd_p2(const ConvArgsP2& a, const FwdPlanP2& p, int W, int up2, int f16, hipStream_t st);
 bool band_is_persistent(const ConvArgsP2& a, const FwdPlanP2& p);   // will launch_fwd_p2 use the persistent kernel?
 
 }  // namespace itcv

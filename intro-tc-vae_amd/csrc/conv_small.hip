@@ -130,7 +130,8 @@ __global__ __launch_bounds__(256) void conv_small_cin_kernel(const float* __rest
 // 1-KB wave-private LDS tile; strips overlap by 4 columns (12 outputs per 16-column strip).
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 
-template <bool DGRAD>
+// F16: fp16 planes (scale record behind them), the register-resident weights split as fp16 planes of 2^8 w.
+template <bool DGRAD, bool F16 = false>
 __global__ __launch_bounds__(256) void conv_small_cout_planes_kernel(const u32x4* __restrict__ xp,
                                                                     const float* __restrict__ w,
                                                                     const float* __restrict__ bias, float* __restrict__ y,
@@ -165,11 +166,12 @@ __global__ __launch_bounds__(256) void conv_small_cout_planes_kernel(const u32x4
           v[j] = t;
         }
         u32x4 pl[2];
-        split8<2>(v, pl);
+        split8<2, F16>(v, pl, F16 ? (float)(1 << kWeightScaleLog2) : 1.f);
         af[dh][hf][0] = __builtin_bit_cast(bf16x8, pl[0]);
         af[dh][hf][1] = __builtin_bit_cast(bf16x8, pl[1]);
       }
   }
+  const float oscale = F16 ? reinterpret_cast<const ScaleRec*>(xp + 2 * plane_stride)->inv * (1.f / (float)(1 << kWeightScaleLog2)) : 1.f;
   const u32x4 zero = {0u, 0u, 0u, 0u};
   // B fragments of one input row: [half][plane], chunk (b, c8 = half*4 + kg, row, wc)
   auto load_row = [&](int hr, u32x4 (&dst)[2][2]) {
@@ -203,9 +205,9 @@ __global__ __launch_bounds__(256) void conv_small_cout_planes_kernel(const u32x4
 #pragma unroll
         for (int hf = 0; hf < 2; ++hf) {
           const bf16x8 b0 = __builtin_bit_cast(bf16x8, cur[hf][0]), b1 = __builtin_bit_cast(bf16x8, cur[hf][1]);
-          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[kh][hf][0], b1, c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[kh][hf][1], b0, c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[kh][hf][0], b0, c, 0, 0, 0);
+          c = mma16x16x32<F16>(af[kh][hf][0], b1, c);
+          c = mma16x16x32<F16>(af[kh][hf][1], b0, c);
+          c = mma16x16x32<F16>(af[kh][hf][0], b0, c);
         }
         acc[slot] = c;
       }
@@ -219,9 +221,10 @@ __global__ __launch_bounds__(256) void conv_small_cout_planes_kernel(const u32x4
         if (lane < 36) {
           const int co = lane / 12, nn = lane - co * 12, wo = s * 12 + nn;
           if (co < CO && wo < W) {
-            float v = bias ? bias[co] : 0.f;
+            float v = (bias && !F16) ? bias[co] : 0.f;
 #pragma unroll
             for (int dw = 0; dw < 5; ++dw) v += zt[(co * 5 + dw) * 17 + nn + dw];
+            if (F16) v = v * oscale + (bias ? bias[co] : 0.f);
             y[(((size_t)b * CO + co) * H + (h0 + o)) * W + wo] = v;
           }
         }
@@ -246,12 +249,14 @@ __global__ __launch_bounds__(256) void conv_small_cout_planes_kernel(const u32x4
 // 30 MFMAs and 32 128-byte store segments.
 typedef float f32x16_t __attribute__((ext_vector_type(16)));
 
-template <int CI, bool DGRAD, int AHEAD>
+// F16: both operands split in registers as fp16 planes: the weights of 2^8 w, the input of Sx x with Sx from `x_amax`
+// (block maxima of |x|, itcv_absmax; null: Sx = 1 -- the stem's input is an image in [0, 1]).
+template <int CI, bool DGRAD, int AHEAD, bool F16 = false>
 __global__ __launch_bounds__(256, 2) void conv_small_cin_mfma_kernel(const float* __restrict__ x,
                                                                  const float* __restrict__ w,
                                                                  const float* __restrict__ bias, float* __restrict__ y,
                                                                  int H, int W, int strips, int row_blocks, int RB,
-                                                                 int njobs) {
+                                                                 int njobs, const float* __restrict__ x_amax) {
   constexpr int KS = 5, KK = 25, M = 64;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int job = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + wv);   // wave-uniform: addresses go to SGPRs
@@ -261,6 +266,11 @@ __global__ __launch_bounds__(256, 2) void conv_small_cin_mfma_kernel(const float
   const int h0 = rbk * RB, w0 = s * 32;
   const int nrows = min(RB, H - h0);
   const size_t HW = (size_t)H * W;
+  float xscale = 1.f, oscale = 1.f;
+  if constexpr (F16) {
+    if (x_amax) xscale = scale_for_bound(wave_absmax_of(x_amax, kAbsmaxParts));
+    oscale = (1.f / (float)(1 << kWeightScaleLog2)) / xscale;      // exact: powers of two
+  }
 
   // this lane's 8 reduction slots k = 8*kg + j -> (dw, ci); slots >= 5*CI are padding
   int k_dw[8], k_ci[8];
@@ -287,7 +297,7 @@ __global__ __launch_bounds__(256, 2) void conv_small_cin_mfma_kernel(const float
         v[j] = t;
       }
       u32x4 pl[2];
-      split8<2>(v, pl);
+      split8<2, F16>(v, pl, F16 ? (float)(1 << kWeightScaleLog2) : 1.f);
       af[dh][mt][0] = __builtin_bit_cast(bf16x8, pl[0]);
       af[dh][mt][1] = __builtin_bit_cast(bf16x8, pl[1]);
     }
@@ -305,7 +315,7 @@ __global__ __launch_bounds__(256, 2) void conv_small_cin_mfma_kernel(const float
     const float* xr = xb + hr * W;
 #pragma unroll
     for (int j = 0; j < 8; ++j) v[j] = (rok && offj[j] >= 0) ? xr[offj[j]] : 0.f;
-    split8<2>(v, dst);
+    split8<2, F16>(v, dst, xscale);
   };
   // ring of R = 5 + AHEAD input-row fragments: slot q holds input row h0 - 2 + i with i % R == q; AHEAD = 1 requests the
   // row that completes output row o + 1 while row o is multiplied
@@ -332,9 +342,9 @@ __global__ __launch_bounds__(256, 2) void conv_small_cin_mfma_kernel(const float
                      b1 = __builtin_bit_cast(bf16x8, ring[(u + dh) % R][1]);
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) {
-          acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[dh][mt][0], b1, acc[mt], 0, 0, 0);
-          acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[dh][mt][1], b0, acc[mt], 0, 0, 0);
-          acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[dh][mt][0], b0, acc[mt], 0, 0, 0);
+          acc[mt] = mma32x32x16<F16>(af[dh][mt][0], b1, acc[mt]);
+          acc[mt] = mma32x32x16<F16>(af[dh][mt][1], b0, acc[mt]);
+          acc[mt] = mma32x32x16<F16>(af[dh][mt][0], b0, acc[mt]);
         }
       }
       float* yr = yb + (size_t)(h0 + o) * W;
@@ -343,7 +353,7 @@ __global__ __launch_bounds__(256, 2) void conv_small_cin_mfma_kernel(const float
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int mu = mt * 32 + (r & 3) + 8 * (r >> 2);   // + 4*kg inside lane_off
-          yr[(size_t)mu * HW + lane_off] = acc[mt][r] + (bias ? bias[mu + 4 * kg] : 0.f);
+          yr[(size_t)mu * HW + lane_off] = (F16 ? acc[mt][r] * oscale : acc[mt][r]) + (bias ? bias[mu + 4 * kg] : 0.f);
         }
     }
   }
@@ -403,8 +413,10 @@ int itcv_conv2d_small_cout_fwd(const float* x, const float* w, const float* bias
 int itcv_conv2d_small_cout_bf16p_supported(int C, int Co, int KS) { return C == 64 && Co >= 1 && Co <= 3 && KS == 5; }
 
 int itcv_conv2d_small_cout_fwd_bf16p(const void* xplanes, const float* w, const float* bias, float* y, int B, int C,
-                                     int H, int W, int Co, int KS, int for_dgrad, void* stream) {
-  ITCV_REQUIRE(xplanes && w && y && B > 0 && H > 0 && W > 0, "itcv_conv2d_small_cout_fwd_bf16p");
+                                     int H, int W, int Co, int KS, int for_dgrad, int ns, void* stream) {
+  ITCV_REQUIRE(xplanes && w && y && B > 0 && H > 0 && W > 0 && (ns == 2 || ns == ITCV_PLANES_F16X2),
+               "itcv_conv2d_small_cout_fwd_bf16p");
+  const bool f16 = ns == ITCV_PLANES_F16X2;
   if (!itcv_conv2d_small_cout_bf16p_supported(C, Co, KS))
     return fail("%s: needs C == 64, Co <= 3, KS == 5", "itcv_conv2d_small_cout_fwd_bf16p");
   const int strips = cdiv(W, 12), RB = H >= 16 ? 16 : H, row_blocks = cdiv(H, RB);
@@ -412,13 +424,19 @@ int itcv_conv2d_small_cout_fwd_bf16p(const void* xplanes, const float* w, const 
   hipStream_t st = S(stream);
   const size_t plane_stride = (size_t)B * 8 * H * W;
   const u32x4* xp = static_cast<const u32x4*>(xplanes);
-  ProfScope prof(st, 4, KS, Co, 0, 2, 2.0 * B * H * W * (double)Co * C * KS * KS);
-  if (for_dgrad)
-    launch_timed(conv_small_cout_planes_kernel<true>, dim3(cdiv(njobs, 4)), dim3(256), 0, st, xp, w, bias, y, B, H, W, Co,
-                 strips, row_blocks, RB, plane_stride, njobs);
-  else
-    launch_timed(conv_small_cout_planes_kernel<false>, dim3(cdiv(njobs, 4)), dim3(256), 0, st, xp, w, bias, y, B, H, W, Co,
-                 strips, row_blocks, RB, plane_stride, njobs);
+  ProfScope prof(st, 4, KS, Co, 0, ns, 2.0 * B * H * W * (double)Co * C * KS * KS);
+  const dim3 grid(cdiv(njobs, 4)), blk(256);
+#define ITCV_SCOUT_P(DG_, F_)                                                                                      \
+  launch_timed((conv_small_cout_planes_kernel<DG_, F_>), grid, blk, 0, st, xp, w, bias, y, B, H, W, Co, strips, \
+               row_blocks, RB, plane_stride, njobs)
+  if (for_dgrad) {
+    if (f16) ITCV_SCOUT_P(true, true);
+    else ITCV_SCOUT_P(true, false);
+  } else {
+    if (f16) ITCV_SCOUT_P(false, true);
+    else ITCV_SCOUT_P(false, false);
+  }
+#undef ITCV_SCOUT_P
   ITCV_CHECK_LAUNCH("itcv_conv2d_small_cout_fwd_bf16p");
   return 0;
 }
@@ -471,8 +489,11 @@ int itcv_conv2d_small_cin_bf16x3_supported(int C, int Co, int KS, int W) {
 }
 
 int itcv_conv2d_small_cin_fwd_bf16x3(const float* x, const float* w, const float* bias, float* y, int B, int C, int H,
-                                     int W, int Co, int KS, int for_dgrad, void* stream) {
-  ITCV_REQUIRE(x && w && y && B > 0 && H > 0 && W > 0, "itcv_conv2d_small_cin_fwd_bf16x3");
+                                     int W, int Co, int KS, int for_dgrad, int ns, const float* x_amax, void* stream) {
+  ITCV_REQUIRE(x && w && y && B > 0 && H > 0 && W > 0 && (ns == 2 || ns == ITCV_PLANES_F16X2),
+               "itcv_conv2d_small_cin_fwd_bf16x3");
+  ITCV_REQUIRE(!x_amax || ns == ITCV_PLANES_F16X2, "itcv_conv2d_small_cin_fwd_bf16x3(a scale only applies to fp16 planes)");
+  const bool f16 = ns == ITCV_PLANES_F16X2;
   if (!itcv_conv2d_small_cin_bf16x3_supported(C, Co, KS, W))
     return fail("%s: needs C <= 3, Co == 64, KS == 5, W %% 32 == 0", "itcv_conv2d_small_cin_fwd_bf16x3");
   const int strips = W / 32;
@@ -484,16 +505,21 @@ int itcv_conv2d_small_cin_fwd_bf16x3(const float* x, const float* w, const float
   row_blocks = cdiv(H, RB);
   const int njobs = B * row_blocks * strips;
   hipStream_t st = S(stream);
-  ProfScope prof(st, 5, KS, C, 0, 2, 2.0 * B * H * W * (double)Co * C * KS * KS);
+  ProfScope prof(st, 5, KS, C, 0, ns, 2.0 * B * H * W * (double)Co * C * KS * KS);
   // (Requesting each input row one output row ahead of its use -- AHEAD = 1 -- was measured slower, 37 -> 43 us at
   // 128 x 3 x 64 x 64: the kernel is bound by its 134 MB of stores, and the longer ring costs registers.)
-#define ITCV_SCIN_K(CI_, DG_)                                                                                       \
-  launch_timed((conv_small_cin_mfma_kernel<CI_, DG_, 0>), dim3(cdiv(njobs, 4)), dim3(256), 0, st, x, w, bias, y, H, W, \
-               strips, row_blocks, RB, njobs)
-#define ITCV_SCIN_M(CI_)                   \
-  do {                                     \
-    if (for_dgrad) ITCV_SCIN_K(CI_, true); \
-    else ITCV_SCIN_K(CI_, false);          \
+#define ITCV_SCIN_K(CI_, DG_, F_)                                                                                       \
+  launch_timed((conv_small_cin_mfma_kernel<CI_, DG_, 0, F_>), dim3(cdiv(njobs, 4)), dim3(256), 0, st, x, w, bias, y, H, W, \
+               strips, row_blocks, RB, njobs, x_amax)
+#define ITCV_SCIN_M(CI_)                             \
+  do {                                               \
+    if (for_dgrad) {                                 \
+      if (f16) ITCV_SCIN_K(CI_, true, true);         \
+      else ITCV_SCIN_K(CI_, true, false);            \
+    } else {                                         \
+      if (f16) ITCV_SCIN_K(CI_, false, true);        \
+      else ITCV_SCIN_K(CI_, false, false);           \
+    }                                                \
   } while (0)
   if (C == 1) ITCV_SCIN_M(1);
   else if (C == 2) ITCV_SCIN_M(2);

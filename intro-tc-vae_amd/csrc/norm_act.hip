@@ -317,12 +317,19 @@ __device__ __forceinline__ void store_planes_wave(u32x4* __restrict__ planes, si
   }
 }
 
-template <int POOL, int NS, bool STATS, bool STRIP = true>
+// F16: the planes are fp16 hi / lo of the output with scale 1 (activations are O(1); common.h), record behind plane 1.
+template <int POOL, int NS, bool STATS, bool STRIP = true, bool F16 = false>
 __global__ __launch_bounds__(256) void bn_act_fwd_planes_kernel(
     const float* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ rstd,
     const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ skip,
     float* __restrict__ y, u32x4* __restrict__ planes, int B, int C, int H, int W, float slope, BnStatsIn st,
     size_t plane_stride, BnGrp grp) {
+  if constexpr (F16) {
+    if (blockIdx.x == 0 && blockIdx.z == 0 && threadIdx.x == 0) {
+      ScaleRec* rec = reinterpret_cast<ScaleRec*>(planes + (size_t)NS * plane_stride);
+      rec->scale = 1.f, rec->inv = 1.f, rec->pad[0] = rec->pad[1] = 0.f;
+    }
+  }
   {
     const size_t g = blockIdx.z;     // BatchNorm group (gridDim.z = 1 and a zero `grp` otherwise)
     x += g * grp.xs, planes += g * grp.ps, mean += g * grp.cs, rstd += g * grp.cs;
@@ -425,7 +432,7 @@ __global__ __launch_bounds__(256) void bn_act_fwd_planes_kernel(
       float v8[8];
 #pragma unroll
       for (int j = 0; j < 8; ++j) v8[j] = o[j][px];
-      split8<NS>(v8, chk[px]);
+      split8<NS, F16>(v8, chk[px]);
     }
     const uint32_t cidx0 = base + (threadIdx.x & ~63u);
     if (STRIP && cidx0 + 64 <= total) {   // whole wave in range (wave-uniform): coalesced plane stores
@@ -540,13 +547,19 @@ struct BnBwdFinal {   // fused single-launch path (splits == 1): the block write
   int accumulate;
 };
 
-template <int MODE, bool FUSED>
+// MX (fp16 gradient planes): the block also records u = |gamma rstd| max|g| and v = max|xhat| over its share, at
+// mx[idx] / mx[nmx + idx], idx = (group * splits + slice) * C + c.  The apply pass turns their maxima U, V into the
+// tensor's scale: |dx| = |gamma rstd| |g - m1 - xhat m2| <= |gamma rstd| G_c (2 + X_c) <= U (2 + V), because
+// |m1| = |mean g| <= G_c and |m2| = |mean g xhat| <= G_c sqrt(mean xhat^2) <= G_c.
+template <int MODE, bool FUSED, bool MX = false>
 __global__ __launch_bounds__(kRedThreads) void bn_bwd_partial_v4(
     const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ mean,
     const float* __restrict__ rstd, const float* __restrict__ gamma, const float* __restrict__ beta,
     const float* __restrict__ skip, double* __restrict__ part, int B, int C, int H, int W, float slope, int splits,
-    int w_shift, int hw_shift, BnBwdFinal f, BnGrp grp) {
+    int w_shift, int hw_shift, BnBwdFinal f, BnGrp grp, float* __restrict__ mx = nullptr, int nmx = 0) {
   __shared__ double scratch[kRedThreads / 64];
+  __shared__ float mscratch[MX ? 2 * (kRedThreads / 64) : 1];
+  const uint32_t gz = FUSED ? 0u : blockIdx.z;
   const uint32_t c = blockIdx.x, s = blockIdx.y, HW = H * W, total = (uint32_t)B * HW;
   const uint32_t chunk = ((total + splits - 1) / splits + 3) & ~3u;
   const uint32_t beg = s * chunk, end = min(beg + chunk, total);
@@ -566,6 +579,7 @@ __global__ __launch_bounds__(kRedThreads) void bn_bwd_partial_v4(
   if (skip && gi) skip += grp.xs;
   const float mu = mean[c], rs = rstd[c];
   double s1 = 0.0, s2 = 0.0;
+  float gmax = 0.f, xmax = 0.f;
 #pragma unroll 2
   for (uint32_t i = beg + threadIdx.x * 4; i < end; i += kRedThreads * 4) {
     const uint32_t b = fdiv(i, HW, hw_shift), hw = i - b * HW;
@@ -586,9 +600,25 @@ __global__ __launch_bounds__(kRedThreads) void bn_bwd_partial_v4(
     if (!(u3 > 0.f)) g.w *= slope;
     s1 += ((double)g.x + (double)g.y) + ((double)g.z + (double)g.w);
     s2 += ((double)g.x * xh0 + (double)g.y * xh1) + ((double)g.z * xh2 + (double)g.w * xh3);
+    if constexpr (MX) {
+      gmax = fmaxf(fmaxf(gmax, fabsf(g.x)), fmaxf(fmaxf(fabsf(g.y), fabsf(g.z)), fabsf(g.w)));
+      xmax = fmaxf(fmaxf(xmax, fabsf(xh0)), fmaxf(fmaxf(fabsf(xh1), fabsf(xh2)), fabsf(xh3)));
+    }
   }
   s1 = block_sum(s1, scratch);
   s2 = block_sum(s2, scratch);
+  if constexpr (MX) {
+    gmax = wave_max(gmax), xmax = wave_max(xmax);
+    if ((threadIdx.x & 63) == 0) mscratch[threadIdx.x >> 6] = gmax, mscratch[kRedThreads / 64 + (threadIdx.x >> 6)] = xmax;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      float gm = 0.f, xm = 0.f;
+      for (int k = 0; k < kRedThreads / 64; ++k) gm = fmaxf(gm, mscratch[k]), xm = fmaxf(xm, mscratch[kRedThreads / 64 + k]);
+      const size_t idx = ((size_t)(FUSED ? (uint32_t)gi : gz) * splits + s) * C + c;
+      mx[idx] = fabsf(ga * rs) * gm, mx[(size_t)nmx + idx] = xm;
+    }
+    __syncthreads();
+  }
   if (threadIdx.x == 0) {
     if (FUSED) {
       f.dsums[c] = s1;
@@ -652,13 +682,32 @@ struct BnBwdSumsIn {
   int accumulate;
 };
 
-template <int MODE, int NS, bool SUMS, bool STRIP = true>
+// F16: dx goes out as fp16 hi / lo planes of S dx.  S is the same in every block of every group of the call: each block
+// takes the maxima U, V of the partial pass's mx arrays (see bn_bwd_partial_v4) and maps the bound U (2 + V) just under
+// 2^15; block 0 of group 0 records {S, 1/S} behind plane 1.
+template <int MODE, int NS, bool SUMS, bool STRIP = true, bool F16 = false>
 __global__ __launch_bounds__(256) void bn_bwd_apply_planes(
     const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ mean,
     const float* __restrict__ rstd, const float* __restrict__ gamma, const float* __restrict__ beta,
     const float* __restrict__ skip, const double* __restrict__ dsums, double count, float* __restrict__ dx,
     float* __restrict__ dskip, u32x4* __restrict__ planes, int B, int C, int H, int W, float slope, int w_shift,
-    BnBwdSumsIn sm, size_t plane_stride, BnGrp grp) {
+    BnBwdSumsIn sm, size_t plane_stride, BnGrp grp, const float* __restrict__ mx = nullptr, int nmx = 0) {
+  float pscale = 1.f;
+  if constexpr (F16) {
+    __shared__ float s_uv[8];
+    float u = 0.f, v = 0.f;
+    for (int i = threadIdx.x; i < nmx; i += 256) u = fmaxf(u, mx[i]), v = fmaxf(v, mx[nmx + i]);
+    u = wave_max(u), v = wave_max(v);
+    if ((threadIdx.x & 63) == 0) s_uv[threadIdx.x >> 6] = u, s_uv[4 + (threadIdx.x >> 6)] = v;
+    __syncthreads();
+    u = fmaxf(fmaxf(s_uv[0], s_uv[1]), fmaxf(s_uv[2], s_uv[3]));
+    v = fmaxf(fmaxf(s_uv[4], s_uv[5]), fmaxf(s_uv[6], s_uv[7]));
+    pscale = scale_for_bound(u * (2.f + v));
+    if (blockIdx.x == 0 && blockIdx.z == 0 && threadIdx.x == 0) {
+      ScaleRec* rec = reinterpret_cast<ScaleRec*>(planes + (size_t)NS * plane_stride);
+      rec->scale = pscale, rec->inv = 1.f / pscale, rec->pad[0] = rec->pad[1] = 0.f;
+    }
+  }
   {
     const size_t g = blockIdx.z;     // BatchNorm group (gridDim.z = 1 and a zero `grp` otherwise)
     x += g * grp.xs, dy += g * grp.dys, planes += g * grp.ps, mean += g * grp.cs, rstd += g * grp.cs;
@@ -738,7 +787,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_planes(
       float v8[8];
 #pragma unroll
       for (int j = 0; j < 8; ++j) v8[j] = o[j][px];
-      split8<NS>(v8, chk[px]);
+      split8<NS, F16>(v8, chk[px], pscale);
     }
     const uint32_t cidx0 = base + (threadIdx.x & ~63u);
     if (STRIP && cidx0 + 64 <= total) {   // whole wave in range (wave-uniform): coalesced plane stores
@@ -841,6 +890,7 @@ static inline int grid_for(size_t n, int per_thread = 1) {
 // box, whole c2 step, against direct stores: 19.75 -> 19.30 ms.  All BatchNorm groups of a layer are issued together and
 // the apply pass folds the per-slice partial sums itself where a thread block covers whole channel groups (the one-launch-
 // per-group and separate-finalize forms of round 2 were diagnostics and are gone).
+static inline bool bn_fmt_ok(int ns) { return ns == 2 || ns == 3 || ns == ITCV_PLANES_F16X2; }
 static inline int bn_splits(int B, int C, int HW) {
   const size_t total = (size_t)B * HW;
   constexpr int target = 1024;   // blocks aimed at by the sliced reductions
@@ -862,7 +912,8 @@ extern "C" {
 
 size_t itcv_bn_workspace(int B, int C, int HW) {
   if (B <= 0 || C <= 0 || HW <= 0) return 0;
-  return (size_t)bn_splits(B, C, HW) * 2 * C * sizeof(double);
+  // per-slice partial sums (fp64) + the per-slice maxima the backward of the fp16 planes format records (two floats)
+  return (size_t)bn_splits(B, C, HW) * 2 * C * (sizeof(double) + sizeof(float));
 }
 
 int itcv_bn_moments(const float* x, double* sums, int B, int C, int HW, void* ws, size_t ws_bytes, void* stream) {
@@ -930,23 +981,25 @@ int itcv_bn_act_fwd(const float* x, const float* mean, const float* rstd, const 
   ITCV_REQUIRE(x && mean && rstd && gamma && beta && (y || planes) && B > 0 && C > 0 && H > 0 && W > 0, "itcv_bn_act_fwd");
   ITCV_REQUIRE((size_t)B * C * H * W < (1ull << 31), "itcv_bn_act_fwd(tensor < 2^31 elements)");
   if (planes) {
-    ITCV_REQUIRE((ns == 2 || ns == 3) && itcv_bn_act_planes_supported(C, H, W, pool), "itcv_bn_act_fwd(planes)");
+    ITCV_REQUIRE(bn_fmt_ok(ns) && itcv_bn_act_planes_supported(C, H, W, pool), "itcv_bn_act_fwd(planes)");
     const size_t threads = (size_t)B * (C / 8) * ((pool ? (H / 2) * (W / 2) : H * W) / (pool ? 2 : 4));
     const dim3 grid(grid_for(threads)), blk(256);
     u32x4* pl = static_cast<u32x4*>(planes);
     const size_t pstride = plane_stride ? plane_stride : (size_t)B * (C / 8) * (pool ? (H / 2) * (W / 2) : H * W);
-#define ITCV_FWD_PLANES(POOL_, NS_)                                                                                   \
+#define ITCV_FWD_PLANES(POOL_, NS_, F_)                                                                               \
   do {                                                                                                                \
-      hipLaunchKernelGGL((bn_act_fwd_planes_kernel<POOL_, NS_, false, true>), grid, blk, 0, S(stream), x, mean, rstd, gamma, \
+      hipLaunchKernelGGL((bn_act_fwd_planes_kernel<POOL_, NS_, false, true, F_>), grid, blk, 0, S(stream), x, mean, rstd, gamma, \
                          beta, skip, y, pl, B, C, H, W, slope, BnStatsIn{}, pstride, BnGrp{});                                   \
   } while (0)
-    if (pool) {
-      if (ns == 2) ITCV_FWD_PLANES(1, 2);
-      else ITCV_FWD_PLANES(1, 3);
-    } else {
-      if (ns == 2) ITCV_FWD_PLANES(0, 2);
-      else ITCV_FWD_PLANES(0, 3);
-    }
+#define ITCV_FWD_PLANES_NS(POOL_)                                   \
+  do {                                                              \
+    if (ns == ITCV_PLANES_F16X2) ITCV_FWD_PLANES(POOL_, 2, true);   \
+    else if (ns == 2) ITCV_FWD_PLANES(POOL_, 2, false);             \
+    else ITCV_FWD_PLANES(POOL_, 3, false);                          \
+  } while (0)
+    if (pool) ITCV_FWD_PLANES_NS(1);
+    else ITCV_FWD_PLANES_NS(0);
+#undef ITCV_FWD_PLANES_NS
 #undef ITCV_FWD_PLANES
     ITCV_CHECK_LAUNCH("itcv_bn_act_fwd(planes)");
     return 0;
@@ -966,10 +1019,12 @@ int itcv_bn_act_fwd(const float* x, const float* mean, const float* rstd, const 
   return 0;
 }
 
-int itcv_bn_act_bwd_reduce(const float* x, const float* dy, const float* mean, const float* rstd, const float* gamma,
+}  // extern "C"
+// mx != NULL (fp16 gradient planes): also record the per-slice maxima, mx[2][splits * C] (see bn_bwd_partial_v4)
+static int bwd_reduce_impl(const float* x, const float* dy, const float* mean, const float* rstd, const float* gamma,
                            const float* beta, const float* skip, double* dsums, float* dgamma, float* dbeta,
                            int accumulate, int B, int C, int H, int W, float slope, int pool, int up2, void* ws,
-                           size_t ws_bytes, void* stream) {
+                           size_t ws_bytes, float* mx, void* stream) {
   ITCV_REQUIRE(x && dy && mean && rstd && gamma && beta && dsums && B > 0 && C > 0, "itcv_bn_act_bwd_reduce");
   ITCV_REQUIRE(!(pool && up2), "itcv_bn_act_bwd_reduce(pool and up2 are exclusive)");
   if (pool) ITCV_REQUIRE(H % 2 == 0 && W % 2 == 0, "itcv_bn_act_bwd_reduce(pool)");
@@ -980,9 +1035,18 @@ int itcv_bn_act_bwd_reduce(const float* x, const float* dy, const float* mean, c
   const bool vec = (W % 4 == 0) && ((size_t)B * C * H * W < (1ull << 31));
   const int wsh = ilog2_exact(W), hwsh = ilog2_exact(H * W);
   hipStream_t st = S(stream);
+  ITCV_REQUIRE(!mx || vec, "itcv_bn_train_bwd(fp16 planes need W % 4 == 0)");
+  const int nmx = splits * C;
 #define ITCV_BWD_PARTIAL(MODE)                                                                                   \
   do {                                                                                                           \
-    if (vec && splits == 1)                                                                                      \
+    if (mx && splits == 1)                                                                                       \
+      hipLaunchKernelGGL((bn_bwd_partial_v4<MODE, true, true>), grid, dim3(kRedThreads), 0, st, x, dy, mean, rstd, \
+                         gamma, beta, skip, part, B, C, H, W, slope, 1, wsh, hwsh,                               \
+                         BnBwdFinal{dsums, dgamma, dbeta, accumulate}, BnGrp{}, mx, nmx);                        \
+    else if (mx)                                                                                                 \
+      hipLaunchKernelGGL((bn_bwd_partial_v4<MODE, false, true>), grid, dim3(kRedThreads), 0, st, x, dy, mean, rstd, \
+                         gamma, beta, skip, part, B, C, H, W, slope, splits, wsh, hwsh, BnBwdFinal{}, BnGrp{}, mx, nmx); \
+    else if (vec && splits == 1)                                                                                 \
       hipLaunchKernelGGL((bn_bwd_partial_v4<MODE, true>), grid, dim3(kRedThreads), 0, st, x, dy, mean, rstd,      \
                          gamma, beta, skip, part, B, C, H, W, slope, 1, wsh, hwsh,                               \
                          BnBwdFinal{dsums, dgamma, dbeta, accumulate}, BnGrp{});                                          \
@@ -1008,11 +1072,11 @@ int itcv_bn_act_bwd_reduce(const float* x, const float* dy, const float* mean, c
   return 0;
 }
 
-int itcv_bn_act_bwd_apply(const float* x, const float* dy, const float* mean, const float* rstd, const float* gamma,
+static int bwd_apply_impl(const float* x, const float* dy, const float* mean, const float* rstd, const float* gamma,
                           const float* beta, const float* skip, const double* dsums, const double* local_dsums,
                           double count, float* dx, float* dskip, float* dgamma, float* dbeta, int accumulate, int B,
                           int C, int H, int W, float slope, int pool, int up2, void* dx_planes, int ns,
-                          size_t plane_stride, void* stream) {
+                          size_t plane_stride, const float* mx, int nmx, void* stream) {
   ITCV_REQUIRE(x && dy && mean && rstd && gamma && beta && dsums && (dx || dx_planes) && B > 0 && C > 0 && count > 0,
                "itcv_bn_act_bwd_apply");
   const size_t pstride = plane_stride ? plane_stride : (size_t)B * (C / 8) * H * W;
@@ -1022,18 +1086,22 @@ int itcv_bn_act_bwd_apply(const float* x, const float* dy, const float* mean, co
   const int wsh = ilog2_exact(W), hwsh = ilog2_exact(H * W), cmask = ilog2_exact(C) >= 0 ? C - 1 : -1;
   hipStream_t st = S(stream);
   if (dx_planes) {
-    ITCV_REQUIRE((ns == 2 || ns == 3) && vec && itcv_bn_act_planes_supported(C, H, W, 0), "itcv_bn_act_bwd_apply(planes)");
+    ITCV_REQUIRE(bn_fmt_ok(ns) && vec && itcv_bn_act_planes_supported(C, H, W, 0), "itcv_bn_act_bwd_apply(planes)");
+    if (ns == ITCV_PLANES_F16X2 && !mx)
+      return fail("%s: fp16 gradient planes take their scale from the maxima of the reduce pass: use itcv_bn_train_bwd",
+                  "itcv_bn_act_bwd_apply");
     const dim3 grid(grid_for(n / 32)), blk(256);
     u32x4* pl = static_cast<u32x4*>(dx_planes);
-#define ITCV_BWD_PLANES(MODE_, NS_)                                                                              \
+#define ITCV_BWD_PLANES(MODE_, NS_, F_)                                                                          \
   do {                                                                                                           \
-      hipLaunchKernelGGL((bn_bwd_apply_planes<MODE_, NS_, false, true>), grid, blk, 0, st, x, dy, mean, rstd, gamma, beta, \
-                         skip, dsums, count, dx, dskip, pl, B, C, H, W, slope, wsh, BnBwdSumsIn{}, pstride, BnGrp{});       \
+      hipLaunchKernelGGL((bn_bwd_apply_planes<MODE_, NS_, false, true, F_>), grid, blk, 0, st, x, dy, mean, rstd, gamma, beta, \
+                         skip, dsums, count, dx, dskip, pl, B, C, H, W, slope, wsh, BnBwdSumsIn{}, pstride, BnGrp{}, mx, nmx); \
   } while (0)
-#define ITCV_BWD_PLANES_NS(MODE_)        \
-  do {                                   \
-    if (ns == 2) ITCV_BWD_PLANES(MODE_, 2); \
-    else ITCV_BWD_PLANES(MODE_, 3);      \
+#define ITCV_BWD_PLANES_NS(MODE_)                                   \
+  do {                                                              \
+    if (ns == ITCV_PLANES_F16X2) ITCV_BWD_PLANES(MODE_, 2, true);   \
+    else if (ns == 2) ITCV_BWD_PLANES(MODE_, 2, false);             \
+    else ITCV_BWD_PLANES(MODE_, 3, false);                          \
   } while (0)
     if (pool) ITCV_BWD_PLANES_NS(1);
     else if (up2) ITCV_BWD_PLANES_NS(2);
@@ -1073,6 +1141,23 @@ int itcv_bn_act_bwd_apply(const float* x, const float* dy, const float* mean, co
   return 0;
 }
 
+extern "C" {
+int itcv_bn_act_bwd_reduce(const float* x, const float* dy, const float* mean, const float* rstd, const float* gamma,
+                           const float* beta, const float* skip, double* dsums, float* dgamma, float* dbeta,
+                           int accumulate, int B, int C, int H, int W, float slope, int pool, int up2, void* ws,
+                           size_t ws_bytes, void* stream) {
+  return bwd_reduce_impl(x, dy, mean, rstd, gamma, beta, skip, dsums, dgamma, dbeta, accumulate, B, C, H, W, slope, pool, up2,
+                         ws, ws_bytes, nullptr, stream);
+}
+int itcv_bn_act_bwd_apply(const float* x, const float* dy, const float* mean, const float* rstd, const float* gamma,
+                          const float* beta, const float* skip, const double* dsums, const double* local_dsums,
+                          double count, float* dx, float* dskip, float* dgamma, float* dbeta, int accumulate, int B,
+                          int C, int H, int W, float slope, int pool, int up2, void* dx_planes, int ns,
+                          size_t plane_stride, void* stream) {
+  return bwd_apply_impl(x, dy, mean, rstd, gamma, beta, skip, dsums, local_dsums, count, dx, dskip, dgamma, dbeta, accumulate,
+                        B, C, H, W, slope, pool, up2, dx_planes, ns, plane_stride, nullptr, 0, stream);
+}
+
 // ---- single-rank training forms: statistics + apply (forward), sums + apply (backward) ----------------------
 // Same results as itcv_bn_train_stats + itcv_bn_act_fwd (resp. itcv_bn_act_bwd_reduce + _apply); where the planes
 // kernels apply and the reduction is sliced, the apply launch folds the slices itself: two launches instead of three.
@@ -1091,7 +1176,7 @@ int itcv_bn_train_fwd(const float* x, const float* gamma, const float* beta, con
     const int HWg = H * W, HWo = pool ? HWg / 4 : HWg;
     const size_t xs = (size_t)B * C * HWg, os = (size_t)B * C * HWo, ps = (size_t)B * (C / 8) * HWo;
     const int gsplits = bn_splits(B, C, HWg);
-    const bool mergeable = !tile_stats && planes && (ns == 2 || ns == 3) && itcv_bn_act_planes_supported(C, H, W, pool) &&
+    const bool mergeable = !tile_stats && planes && bn_fmt_ok(ns) && itcv_bn_act_planes_supported(C, H, W, pool) &&
                            xs < (1ull << 31);
     const bool merged = mergeable && gsplits == 1;
     if (mergeable && gsplits > 1 && ws && ws_bytes >= (size_t)groups * gsplits * 2 * C * sizeof(double)) {
@@ -1115,24 +1200,23 @@ int itcv_bn_train_fwd(const float* x, const float* gamma, const float* beta, con
       const size_t threads = (size_t)B * (C / 8) * (HWo / (pool ? 2 : 4));
       const dim3 grid(grid_for(threads), 1, groups), blk(256);
       u32x4* pl = static_cast<u32x4*>(planes);
-#define ITCV_FWD_GRP2_K(POOL_, NS_, ST_, STRIP_)                                                                          \
-  hipLaunchKernelGGL((bn_act_fwd_planes_kernel<POOL_, NS_, ST_, STRIP_>), grid, blk, 0, S(stream), x, mean, rstd, gamma, beta, \
+#define ITCV_FWD_GRP2_K(POOL_, NS_, ST_, F_)                                                                              \
+  hipLaunchKernelGGL((bn_act_fwd_planes_kernel<POOL_, NS_, ST_, true, F_>), grid, blk, 0, S(stream), x, mean, rstd, gamma, beta, \
                      skip, y, pl, B, C, H, W, slope, (ST_) ? stg : BnStatsIn{}, plane_stride, grp)
-#define ITCV_FWD_GRP2(POOL_, NS_)                                                                                         \
-  do {                                                                                                                    \
-    if (fold_in_apply) {                                                                                                  \
-      ITCV_FWD_GRP2_K(POOL_, NS_, true, true);                                                                 \
-    } else {                                                                                                              \
-      ITCV_FWD_GRP2_K(POOL_, NS_, false, true);                                                                \
-    }                                                                                                                     \
+#define ITCV_FWD_GRP2(POOL_, NS_, F_)                                  \
+  do {                                                                 \
+    if (fold_in_apply) ITCV_FWD_GRP2_K(POOL_, NS_, true, F_);          \
+    else ITCV_FWD_GRP2_K(POOL_, NS_, false, F_);                       \
   } while (0)
-      if (pool) {
-        if (ns == 2) ITCV_FWD_GRP2(1, 2);
-        else ITCV_FWD_GRP2(1, 3);
-      } else {
-        if (ns == 2) ITCV_FWD_GRP2(0, 2);
-        else ITCV_FWD_GRP2(0, 3);
-      }
+#define ITCV_FWD_GRP2_NS(POOL_)                                     \
+  do {                                                              \
+    if (ns == ITCV_PLANES_F16X2) ITCV_FWD_GRP2(POOL_, 2, true);     \
+    else if (ns == 2) ITCV_FWD_GRP2(POOL_, 2, false);               \
+    else ITCV_FWD_GRP2(POOL_, 3, false);                            \
+  } while (0)
+      if (pool) ITCV_FWD_GRP2_NS(1);
+      else ITCV_FWD_GRP2_NS(0);
+#undef ITCV_FWD_GRP2_NS
 #undef ITCV_FWD_GRP2_K
 #undef ITCV_FWD_GRP2
       ITCV_CHECK_LAUNCH("itcv_bn_train_fwd(grouped apply)");
@@ -1156,18 +1240,20 @@ int itcv_bn_train_fwd(const float* x, const float* gamma, const float* beta, con
     const size_t threads = (size_t)B * (C / 8) * (HWo / (pool ? 2 : 4));
     const dim3 grid(grid_for(threads), 1, groups), blk(256);
     u32x4* pl = static_cast<u32x4*>(planes);
-#define ITCV_FWD_GRP(POOL_, NS_)                                                                                          \
+#define ITCV_FWD_GRP(POOL_, NS_, F_)                                                                                      \
   do {                                                                                                                    \
-      hipLaunchKernelGGL((bn_act_fwd_planes_kernel<POOL_, NS_, false, true>), grid, blk, 0, S(stream), x, mean, rstd, gamma,   \
+      hipLaunchKernelGGL((bn_act_fwd_planes_kernel<POOL_, NS_, false, true, F_>), grid, blk, 0, S(stream), x, mean, rstd, gamma, \
                          beta, skip, y, pl, B, C, H, W, slope, BnStatsIn{}, plane_stride, grp);                             \
   } while (0)
-    if (pool) {
-      if (ns == 2) ITCV_FWD_GRP(1, 2);
-      else ITCV_FWD_GRP(1, 3);
-    } else {
-      if (ns == 2) ITCV_FWD_GRP(0, 2);
-      else ITCV_FWD_GRP(0, 3);
-    }
+#define ITCV_FWD_GRP_NS(POOL_)                                     \
+  do {                                                             \
+    if (ns == ITCV_PLANES_F16X2) ITCV_FWD_GRP(POOL_, 2, true);     \
+    else if (ns == 2) ITCV_FWD_GRP(POOL_, 2, false);               \
+    else ITCV_FWD_GRP(POOL_, 3, false);                            \
+  } while (0)
+    if (pool) ITCV_FWD_GRP_NS(1);
+    else ITCV_FWD_GRP_NS(0);
+#undef ITCV_FWD_GRP_NS
 #undef ITCV_FWD_GRP
     ITCV_CHECK_LAUNCH("itcv_bn_train_fwd(grouped apply)");
     return 0;
@@ -1182,7 +1268,7 @@ int itcv_bn_train_fwd(const float* x, const float* gamma, const float* beta, con
   }
   const int HW = H * W, splits = bn_splits(B, C, HW);
   const int per_plane = pool ? (HW / 4) / 2 : HW / 4;
-  const bool fusable = planes && (ns == 2 || ns == 3) && itcv_bn_act_planes_supported(C, H, W, pool) && splits > 1 &&
+  const bool fusable = planes && bn_fmt_ok(ns) && itcv_bn_act_planes_supported(C, H, W, pool) && splits > 1 &&
                        per_plane >= 64 && (size_t)B * C * HW < (1ull << 31);
   if (!fusable) {
     if (int e = itcv_bn_train_stats(x, B, C, HW, eps, momentum, running_mean, running_var, num_batches_tracked, mean,
@@ -1199,18 +1285,20 @@ int itcv_bn_train_fwd(const float* x, const float* gamma, const float* beta, con
   const size_t threads = (size_t)B * (C / 8) * per_plane;
   const dim3 grid(grid_for(threads)), blk(256);
   u32x4* pl = static_cast<u32x4*>(planes);
-#define ITCV_FWD_FUSED(POOL_, NS_)                                                                                   \
+#define ITCV_FWD_FUSED(POOL_, NS_, F_)                                                                               \
   do {                                                                                                                \
-      hipLaunchKernelGGL((bn_act_fwd_planes_kernel<POOL_, NS_, true, true>), grid, blk, 0, S(stream), x, mean, rstd, gamma,  \
+      hipLaunchKernelGGL((bn_act_fwd_planes_kernel<POOL_, NS_, true, true, F_>), grid, blk, 0, S(stream), x, mean, rstd, gamma, \
                          beta, skip, y, pl, B, C, H, W, slope, st, pstride, BnGrp{});                                            \
   } while (0)
-  if (pool) {
-    if (ns == 2) ITCV_FWD_FUSED(1, 2);
-    else ITCV_FWD_FUSED(1, 3);
-  } else {
-    if (ns == 2) ITCV_FWD_FUSED(0, 2);
-    else ITCV_FWD_FUSED(0, 3);
-  }
+#define ITCV_FWD_FUSED_NS(POOL_)                                     \
+  do {                                                               \
+    if (ns == ITCV_PLANES_F16X2) ITCV_FWD_FUSED(POOL_, 2, true);     \
+    else if (ns == 2) ITCV_FWD_FUSED(POOL_, 2, false);               \
+    else ITCV_FWD_FUSED(POOL_, 3, false);                            \
+  } while (0)
+  if (pool) ITCV_FWD_FUSED_NS(1);
+  else ITCV_FWD_FUSED_NS(0);
+#undef ITCV_FWD_FUSED_NS
 #undef ITCV_FWD_FUSED
   ITCV_CHECK_LAUNCH("itcv_bn_train_fwd(apply)");
   return 0;
@@ -1229,9 +1317,17 @@ int itcv_bn_train_bwd(const float* x, const float* dy, const float* mean, const 
     const size_t xs = (size_t)B * C * HWg, dys = pool ? xs / 4 : (up2 ? xs * 4 : xs), ps = (size_t)B * (C / 8) * HWg;
     const bool vecg = (W % 4 == 0) && xs < (1ull << 31);
     const int gsplits = bn_splits(B, C, HWg);
-    const bool mergeable = vecg && dx_planes && (ns == 2 || ns == 3) && itcv_bn_act_planes_supported(C, H, W, 0) ;
+    const bool mergeable = vecg && dx_planes && bn_fmt_ok(ns) && itcv_bn_act_planes_supported(C, H, W, 0);
     const bool merged = mergeable && gsplits == 1;
-    if (mergeable && gsplits > 1 && ws && ws_bytes >= (size_t)groups * gsplits * 2 * C * sizeof(double)) {
+    const bool f16 = ns == ITCV_PLANES_F16X2;
+    // fp16 planes: the maxima of all groups ([2][groups * gsplits * C] floats) follow the partial sums in the workspace
+    const int nmx = groups * gsplits * C;
+    const size_t ws_need = (size_t)groups * gsplits * 2 * C * sizeof(double) + (f16 ? (size_t)2 * nmx * sizeof(float) : 0);
+    float* mx = f16 && ws ? reinterpret_cast<float*>(static_cast<double*>(ws) + (size_t)groups * gsplits * 2 * C) : nullptr;
+    if (f16 && !(mergeable && ws && ws_bytes >= ws_need))
+      return fail("%s: fp16 gradient planes need the merged group path (W %% 4 == 0, planes, a workspace of itcv_bn_workspace * groups)",
+                  "itcv_bn_train_bwd");
+    if (mergeable && gsplits > 1 && ws && ws_bytes >= ws_need) {
       if (pool) ITCV_REQUIRE(H % 2 == 0 && W % 2 == 0, "itcv_bn_train_bwd(pool)");
       const BnGrp grp{xs, 0, dys, ps, C, groups};
       hipStream_t st = S(stream);
@@ -1242,26 +1338,27 @@ int itcv_bn_train_bwd(const float* x, const float* dy, const float* mean, const 
       const double count = (double)B * HWg;
       const bool fold_in_apply = HWg / 4 >= 64;   // the apply pass folds the partial sums itself
       const BnBwdSumsIn smg{part, gsplits, dsums, dgamma, dbeta, accumulate};
-#define ITCV_BWD_GRP2_K(MODE_, NS_, SUMS_, STRIP_)                                                                       \
-  hipLaunchKernelGGL((bn_bwd_apply_planes<MODE_, NS_, SUMS_, STRIP_>), agrid, blk, 0, st, x, dy, mean, rstd, gamma, beta,  \
+#define ITCV_BWD_GRP2_K(MODE_, NS_, SUMS_, F_)                                                                           \
+  hipLaunchKernelGGL((bn_bwd_apply_planes<MODE_, NS_, SUMS_, true, F_>), agrid, blk, 0, st, x, dy, mean, rstd, gamma, beta, \
                      skip, (SUMS_) ? static_cast<const double*>(nullptr) : dsums, count, dx, dskip, pl, B, C, H, W, slope, \
-                     wsh, (SUMS_) ? smg : BnBwdSumsIn{}, plane_stride, grp)
-#define ITCV_BWD_GRP2(MODE_, NS_)                                                                                        \
+                     wsh, (SUMS_) ? smg : BnBwdSumsIn{}, plane_stride, grp, mx, nmx)
+#define ITCV_BWD_GRP2(MODE_, NS_, F_)                                                                                    \
   do {                                                                                                                   \
-    hipLaunchKernelGGL((bn_bwd_partial_v4<MODE_, false>), rgrid, dim3(kRedThreads), 0, st, x, dy, mean, rstd, gamma, beta,  \
-                       skip, part, B, C, H, W, slope, gsplits, wsh, hwsh, BnBwdFinal{}, grp);                            \
+    hipLaunchKernelGGL((bn_bwd_partial_v4<MODE_, false, F_>), rgrid, dim3(kRedThreads), 0, st, x, dy, mean, rstd, gamma, beta, \
+                       skip, part, B, C, H, W, slope, gsplits, wsh, hwsh, BnBwdFinal{}, grp, mx, nmx);                   \
     if (fold_in_apply) {                                                                                                 \
-      ITCV_BWD_GRP2_K(MODE_, NS_, true, true);                                                               \
+      ITCV_BWD_GRP2_K(MODE_, NS_, true, F_);                                                                             \
     } else {                                                                                                             \
       hipLaunchKernelGGL(bn_combine_param_groups_kernel, dim3(cdiv(C, 256)), dim3(256), 0, st, part, dsums, C, gsplits,   \
                          groups, dgamma, dbeta, accumulate);                                                             \
-      ITCV_BWD_GRP2_K(MODE_, NS_, false, true);                                                              \
+      ITCV_BWD_GRP2_K(MODE_, NS_, false, F_);                                                                            \
     }                                                                                                                    \
   } while (0)
-#define ITCV_BWD_GRP2_NS(MODE_)            \
-  do {                                     \
-    if (ns == 2) ITCV_BWD_GRP2(MODE_, 2);  \
-    else ITCV_BWD_GRP2(MODE_, 3);          \
+#define ITCV_BWD_GRP2_NS(MODE_)                          \
+  do {                                                   \
+    if (f16) ITCV_BWD_GRP2(MODE_, 2, true);              \
+    else if (ns == 2) ITCV_BWD_GRP2(MODE_, 2, false);    \
+    else ITCV_BWD_GRP2(MODE_, 3, false);                 \
   } while (0)
       if (pool) ITCV_BWD_GRP2_NS(1);
       else if (up2) ITCV_BWD_GRP2_NS(2);
@@ -1291,17 +1388,18 @@ int itcv_bn_train_bwd(const float* x, const float* dy, const float* mean, const 
     const dim3 rgrid(C, 1), agrid(grid_for(xs / 32), 1, groups), blk(256);
     u32x4* pl = static_cast<u32x4*>(dx_planes);
     const double count = (double)B * HWg;
-#define ITCV_BWD_GRP(MODE_, NS_)                                                                                         \
+#define ITCV_BWD_GRP(MODE_, NS_, F_)                                                                                     \
   do {                                                                                                                   \
-    hipLaunchKernelGGL((bn_bwd_partial_v4<MODE_, true>), rgrid, dim3(kRedThreads), 0, st, x, dy, mean, rstd, gamma, beta,   \
-                       skip, static_cast<double*>(nullptr), B, C, H, W, slope, 1, wsh, hwsh, bf, grp);                   \
-      hipLaunchKernelGGL((bn_bwd_apply_planes<MODE_, NS_, false, true>), agrid, blk, 0, st, x, dy, mean, rstd, gamma, beta,  \
-                         skip, dsums, count, dx, dskip, pl, B, C, H, W, slope, wsh, BnBwdSumsIn{}, plane_stride, grp);     \
+    hipLaunchKernelGGL((bn_bwd_partial_v4<MODE_, true, F_>), rgrid, dim3(kRedThreads), 0, st, x, dy, mean, rstd, gamma, beta, \
+                       skip, static_cast<double*>(nullptr), B, C, H, W, slope, 1, wsh, hwsh, bf, grp, mx, nmx);          \
+      hipLaunchKernelGGL((bn_bwd_apply_planes<MODE_, NS_, false, true, F_>), agrid, blk, 0, st, x, dy, mean, rstd, gamma, beta, \
+                         skip, dsums, count, dx, dskip, pl, B, C, H, W, slope, wsh, BnBwdSumsIn{}, plane_stride, grp, mx, nmx); \
   } while (0)
-#define ITCV_BWD_GRP_NS(MODE_)            \
-  do {                                    \
-    if (ns == 2) ITCV_BWD_GRP(MODE_, 2);  \
-    else ITCV_BWD_GRP(MODE_, 3);          \
+#define ITCV_BWD_GRP_NS(MODE_)                          \
+  do {                                                  \
+    if (f16) ITCV_BWD_GRP(MODE_, 2, true);              \
+    else if (ns == 2) ITCV_BWD_GRP(MODE_, 2, false);    \
+    else ITCV_BWD_GRP(MODE_, 3, false);                 \
   } while (0)
     if (pool) ITCV_BWD_GRP_NS(1);
     else if (up2) ITCV_BWD_GRP_NS(2);
@@ -1314,17 +1412,22 @@ int itcv_bn_train_bwd(const float* x, const float* dy, const float* mean, const 
   const int HW = H * W, splits = bn_splits(B, C, HW);
   const size_t n = (size_t)B * C * HW;
   const bool vec = (W % 4 == 0) && n < (1ull << 31);
-  const bool fusable = dx_planes && (ns == 2 || ns == 3) && vec && itcv_bn_act_planes_supported(C, H, W, 0) &&
+  const bool fusable = dx_planes && bn_fmt_ok(ns) && vec && itcv_bn_act_planes_supported(C, H, W, 0) &&
                        splits > 1 && HW / 4 >= 64;
+  const bool f16 = dx_planes && ns == ITCV_PLANES_F16X2;
+  const int nmx = splits * C;
+  const size_t ws_need = (size_t)splits * 2 * C * sizeof(double) + (f16 ? (size_t)2 * nmx * sizeof(float) : 0);
+  if (f16) ITCV_REQUIRE(ws && ws_bytes >= ws_need, "itcv_bn_train_bwd(workspace, fp16 planes)");
+  float* mx = f16 ? reinterpret_cast<float*>(static_cast<double*>(ws) + (size_t)splits * 2 * C) : nullptr;
   if (!fusable) {
-    if (int e = itcv_bn_act_bwd_reduce(x, dy, mean, rstd, gamma, beta, skip, dsums, dgamma, dbeta, accumulate, B, C, H, W,
-                                       slope, pool, up2, ws, ws_bytes, stream))
+    if (int e = bwd_reduce_impl(x, dy, mean, rstd, gamma, beta, skip, dsums, dgamma, dbeta, accumulate, B, C, H, W, slope,
+                                pool, up2, ws, ws_bytes, mx, stream))
       return e;
-    return itcv_bn_act_bwd_apply(x, dy, mean, rstd, gamma, beta, skip, dsums, nullptr, (double)B * HW, dx, dskip, nullptr,
-                                 nullptr, 0, B, C, H, W, slope, pool, up2, dx_planes, ns, plane_stride, stream);
+    return bwd_apply_impl(x, dy, mean, rstd, gamma, beta, skip, dsums, nullptr, (double)B * HW, dx, dskip, nullptr, nullptr,
+                          0, B, C, H, W, slope, pool, up2, dx_planes, ns, plane_stride, mx, nmx, stream);
   }
   if (pool) ITCV_REQUIRE(H % 2 == 0 && W % 2 == 0, "itcv_bn_train_bwd(pool)");
-  ITCV_REQUIRE(ws && ws_bytes >= (size_t)splits * 2 * C * sizeof(double), "itcv_bn_train_bwd(workspace)");
+  ITCV_REQUIRE(ws && ws_bytes >= ws_need, "itcv_bn_train_bwd(workspace)");
   double* part = static_cast<double*>(ws);
   hipStream_t st = S(stream);
   const int wsh = ilog2_exact(W), hwsh = ilog2_exact(HW);
@@ -1333,18 +1436,19 @@ int itcv_bn_train_bwd(const float* x, const float* dy, const float* mean, const 
   u32x4* pl = static_cast<u32x4*>(dx_planes);
   const double count = (double)B * HW;
   const size_t pstride = plane_stride ? plane_stride : (size_t)B * (C / 8) * HW;
-#define ITCV_BWD_FUSED(MODE_, NS_)                                                                                    \
+#define ITCV_BWD_FUSED(MODE_, NS_, F_)                                                                                \
   do {                                                                                                                \
-    hipLaunchKernelGGL((bn_bwd_partial_v4<MODE_, false>), rgrid, dim3(kRedThreads), 0, st, x, dy, mean, rstd, gamma,   \
-                       beta, skip, part, B, C, H, W, slope, splits, wsh, hwsh, BnBwdFinal{}, BnGrp{});                         \
-      hipLaunchKernelGGL((bn_bwd_apply_planes<MODE_, NS_, true, true>), agrid, blk, 0, st, x, dy, mean, rstd, gamma, beta, \
+    hipLaunchKernelGGL((bn_bwd_partial_v4<MODE_, false, F_>), rgrid, dim3(kRedThreads), 0, st, x, dy, mean, rstd, gamma, \
+                       beta, skip, part, B, C, H, W, slope, splits, wsh, hwsh, BnBwdFinal{}, BnGrp{}, mx, nmx);       \
+      hipLaunchKernelGGL((bn_bwd_apply_planes<MODE_, NS_, true, true, F_>), agrid, blk, 0, st, x, dy, mean, rstd, gamma, beta, \
                          skip, static_cast<const double*>(nullptr), count, dx, dskip, pl, B, C, H, W, slope, wsh, sm,   \
-                         pstride, BnGrp{});                                                                                     \
+                         pstride, BnGrp{}, mx, nmx);                                                                  \
   } while (0)
-#define ITCV_BWD_FUSED_NS(MODE_)            \
-  do {                                      \
-    if (ns == 2) ITCV_BWD_FUSED(MODE_, 2);  \
-    else ITCV_BWD_FUSED(MODE_, 3);          \
+#define ITCV_BWD_FUSED_NS(MODE_)                          \
+  do {                                                    \
+    if (f16) ITCV_BWD_FUSED(MODE_, 2, true);              \
+    else if (ns == 2) ITCV_BWD_FUSED(MODE_, 2, false);    \
+    else ITCV_BWD_FUSED(MODE_, 3, false);                 \
   } while (0)
   if (pool) ITCV_BWD_FUSED_NS(1);
   else if (up2) ITCV_BWD_FUSED_NS(2);

@@ -19,7 +19,7 @@ PKG_ROOT = os.path.dirname(_HERE)
 # ITCV_LIB: load another build of the same library (the -DITCV_DIAG diagnostic build of `make diag`, tools/abl.sh)
 LIB_PATH = os.environ.get("ITCV_LIB") or os.path.join(PKG_ROOT, "lib", "libitcv_hip.so")
 CSRC = os.path.join(PKG_ROOT, "csrc")
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 p, i32, i64, sz, f32, f64 = (ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_size_t,
                              ctypes.c_float, ctypes.c_double)
@@ -48,28 +48,30 @@ SIGNATURES = {
     "itcv_conv2d_fwd_bf16s": (i32, [p, p, p, p] + [i32] * 8 + [p, sz, p]),
     "itcv_planes_bytes": (sz, [i32] * 4),
     "itcv_split_planes": (i32, [p, p, i32, i32, i32, i32, p]),
+    "itcv_absmax": (i32, [p, sz, p, p]),
+    "itcv_split_planes_scaled": (i32, [p, p, i32, i32, i32, i32, p, p]),
     "itcv_conv2d_fwd_bf16p_workspace": (sz, [i32] * 7),
     "itcv_conv2d_fwd_bf16p": (i32, [p, p, p, p] + [i32] * 8 + [p, sz, p]),
     "itcv_conv2d_fwd_bf16p_stat_tiles": (i32, [i32] * 7),
     "itcv_conv2d_fwd_bf16p_st": (i32, [p, p, p, p] + [i32] * 8 + [p, p, sz, p]),
     "itcv_conv2d_wgrad_bf16p_supported": (i32, [i32] * 6),
     "itcv_conv2d_wgrad_bf16p_workspace": (sz, [i32] * 6),
-    "itcv_conv2d_wgrad_bf16p": (i32, [p, p, p] + [i32] * 8 + [p, sz, p]),
+    "itcv_conv2d_wgrad_bf16p": (i32, [p, p, p] + [i32] * 9 + [p, sz, p]),
     "itcv_linear_workspace": (sz, [i32] * 3),
     "itcv_linear_fwd": (i32, [p, p, p, p, i32, i32, i32, p, sz, p]),
     "itcv_linear_dgrad": (i32, [p, p, p, i32, i32, i32, p, sz, p]),
     "itcv_linear_wgrad": (i32, [p, p, p, i32, i32, i32, i32, p, sz, p]),
     "itcv_conv2d_wgrad5_bf16p_supported": (i32, [i32] * 4),
     "itcv_conv2d_wgrad5_bf16p_workspace": (sz, [i32, i32]),
-    "itcv_conv2d_wgrad5_bf16p": (i32, [p, p, p] + [i32] * 6 + [p, sz, p]),
+    "itcv_conv2d_wgrad5_bf16p": (i32, [p, p, p] + [i32] * 6 + [p, i32, p, sz, p]),
     "itcv_conv2d_small_cout_supported": (i32, [i32, i32]),
     "itcv_conv2d_small_cout_bf16p_supported": (i32, [i32, i32, i32]),
-    "itcv_conv2d_small_cout_fwd_bf16p": (i32, [p, p, p, p] + [i32] * 7 + [p]),
+    "itcv_conv2d_small_cout_fwd_bf16p": (i32, [p, p, p, p] + [i32] * 8 + [p]),
     "itcv_conv2d_small_cout_fwd": (i32, [p, p, p, p] + [i32] * 7 + [p]),
     "itcv_conv2d_small_cin_supported": (i32, [i32, i32]),
     "itcv_conv2d_small_cin_fwd": (i32, [p, p, p, p] + [i32] * 7 + [p]),
     "itcv_conv2d_small_cin_bf16x3_supported": (i32, [i32, i32, i32, i32]),
-    "itcv_conv2d_small_cin_fwd_bf16x3": (i32, [p, p, p, p] + [i32] * 7 + [p]),
+    "itcv_conv2d_small_cin_fwd_bf16x3": (i32, [p, p, p, p] + [i32] * 8 + [p, p]),
     "itcv_conv2d_wgrad_bf16s_supported": (i32, [i32] * 5),
     "itcv_conv2d_wgrad_bf16s": (i32, [p, p, p] + [i32] * 8 + [p, sz, p]),
     "itcv_conv2d_wgrad_workspace": (sz, [i32] * 6),

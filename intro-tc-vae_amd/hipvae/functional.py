@@ -96,11 +96,18 @@ def bump_weight_epoch(params=None):
         _PARAM_EPOCH[id(p)] = _PARAM_EPOCH.get(id(p), 0) + 1
 
 
-_NS = {"fp32": 0, "bf16x3": 2, "bf16x6": 3}
+# conv arithmetic -> plane format code of the C ABI (include/itcv_hip.h): 2 / 3 bf16 planes, 4 = two fp16 planes + scale
+_NS = {"fp32": 0, "bf16x3": 2, "bf16x6": 3, "f16x3": 4}
+F16X2 = 4
 import os as _os
 
 _CONV_MATH = [_os.environ.get("ITCV_CONV_MATH", "fp32")]   # the one documented environment override (with ITCV_DDP_GRAPH, ITCV_LIB)
-assert _CONV_MATH[0] in _NS, "ITCV_CONV_MATH must be one of fp32 / bf16x3 / bf16x6"
+assert _CONV_MATH[0] in _NS, "ITCV_CONV_MATH must be one of fp32 / bf16x3 / bf16x6 / f16x3"
+
+
+def _two(ns):
+    """Two-plane formats (bf16x3, f16x3): the ones the weight-gradient and 5x5 planes kernels take."""
+    return ns in (2, F16X2)
 
 
 # Module switches used by the test matrix (never read from the environment):
@@ -114,7 +121,10 @@ def set_conv_math(mode):
     'fp32'   exact fp32 MFMA (v_mfma_f32_32x32x2_f32) -- the parity path and the default;
     'bf16x6' operands split into 3 bf16 planes, 6 bf16 MFMAs per product, fp32 accumulate: fp32-class
              accuracy (~2^-23 per product) at 2.7x the matrix-core rate;
-    'bf16x3' 2 planes / 3 MFMAs: ~2^-16 per product at 5.3x the matrix-core rate.
+    'bf16x3' 2 planes / 3 MFMAs: ~2^-16 per product at 5.3x the matrix-core rate;
+    'f16x3'  2 FP16 planes (hi, lo of the tensor times a power-of-two scale) / the same 3 MFMAs on the fp16 matrix
+             cores: 22 significand bits, ~2^-21 per product -- fp32 class at the bf16x3 rate.  Shapes outside the planes
+             kernels run on the exact fp32 kernels in this mode.
     Layers the split kernel does not cover (3-channel stem/predict, KS=5) stay on the fp32 kernel."""
     assert mode in _NS, mode
     _CONV_MATH[0] = mode
@@ -260,16 +270,19 @@ def conv_apply(x, weight, w4, for_dgrad, bias, B, Ci, H, W, Co, KS, up2):
     if not up2 and lib.itcv_conv2d_small_cin_supported(Ci, KS):
         # <= 4 reduction channels: direct fp32 conv, the pixel's input window lives in registers
         y = torch.empty((B, Co, H, W), dtype=F32, device=x.device)
-        if _SCIN_MFMA[0] and _NS[_CONV_MATH[0]] == 2 and lib.itcv_conv2d_small_cin_bf16x3_supported(Ci, Co, KS, W):
+        fmt = _NS[_CONV_MATH[0]]
+        if _SCIN_MFMA[0] and _two(fmt) and lib.itcv_conv2d_small_cin_bf16x3_supported(Ci, Co, KS, W):
+            # fp16 form: the data-gradient's input is a gradient tensor -> scale from its magnitude (device side)
+            amax = absmax_parts(x) if (fmt == F16X2 and for_dgrad) else None
             call("itcv_conv2d_small_cin_fwd_bf16x3", ptr(x), ptr(w4), ptr(bias), ptr(y), B, Ci, H, W, Co, KS,
-                 int(for_dgrad), stream())
+                 int(for_dgrad), fmt, ptr(amax), stream())
             return y
 
         call("itcv_conv2d_small_cin_fwd", ptr(x), ptr(w4), ptr(bias), ptr(y), B, Ci, H, W, Co, KS, int(for_dgrad),
              stream())
         return y
     ns = _NS[_CONV_MATH[0]]
-    if ns and lib.itcv_conv2d_bf16s_supported(Ci, Co, KS):
+    if ns in (2, 3) and lib.itcv_conv2d_bf16s_supported(Ci, Co, KS):
         wp = packed_weight(weight, w4, for_dgrad, ns)
         y = torch.empty((B, Co, H, W), dtype=F32, device=x.device)
         nws = lib.itcv_conv2d_fwd_bf16s_workspace(B, Ci, H, W, Co, KS)
@@ -281,14 +294,26 @@ def conv_apply(x, weight, w4, for_dgrad, bias, B, Ci, H, W, Co, KS, up2):
     return conv_fwd_raw(x, packed_weight(weight, w4, for_dgrad), bias, B, Ci, H, W, Co, KS, up2)
 
 
-def split_planes(x, ns):
-    """fp32 [B,C,H,W] -> pre-split bf16 planes [ns][B][C/8][H][W] x 16 B (see include/itcv_hip.h)."""
+def absmax_parts(x):
+    """256 block maxima of |x| (device side): what the fp16 split kernels derive a gradient tensor's scale from."""
+    parts = torch.empty(256, dtype=F32, device=x.device)
+    call("itcv_absmax", ptr(x), x.numel(), ptr(parts), stream())
+    return parts
+
+
+def split_planes(x, ns, gradient=False):
+    """fp32 [B,C,H,W] -> pre-split planes [planes][B][C/8][H][W] x 16 B in format ``ns`` (see include/itcv_hip.h).
+    fp16 planes (ns = 4): activations are split with scale 1; a ``gradient`` tensor (arbitrary magnitude) with the
+    power-of-two scale that maps its largest element just under 2^15 (two launches: maxima, split)."""
     B, C, H, W = x.shape
     nbytes = lib.itcv_planes_bytes(B, C, H * W, ns)
     if not nbytes:
         raise abi.HipExtensionError(f"split_planes: unsupported shape {tuple(x.shape)} / ns={ns}")
     xp = torch.empty(nbytes // 4, dtype=torch.int32, device=x.device)
-    call("itcv_split_planes", ptr(x), ptr(xp), B, C, H * W, ns, stream())
+    if ns == F16X2 and gradient:
+        call("itcv_split_planes_scaled", ptr(x), ptr(xp), B, C, H * W, ns, ptr(absmax_parts(x)), stream())
+    else:
+        call("itcv_split_planes", ptr(x), ptr(xp), B, C, H * W, ns, stream())
     return xp
 
 
@@ -303,10 +328,10 @@ def conv_apply_planes(xp, weight, w4, for_dgrad, bias, B, Ci, H, W, Co, KS, up2,
     """conv_apply with the input given as pre-split planes (LDS-DMA kernel, no gather).  ``want_stats``: where the
     kernel can, it also leaves the per-tile channel sums of its output for the BatchNorm that follows
     (attached to the result as ``_itcv_tile_stats``; BnActFn then skips its own statistics pass)."""
-    if not up2 and ns == 2 and lib.itcv_conv2d_small_cout_bf16p_supported(Ci, Co, KS):
+    if not up2 and _two(ns) and lib.itcv_conv2d_small_cout_bf16p_supported(Ci, Co, KS):
         y = torch.empty((B, Co, H, W), dtype=F32, device=xp.device)
         call("itcv_conv2d_small_cout_fwd_bf16p", ptr(xp), ptr(w4), ptr(bias), ptr(y), B, Ci, H, W, Co, KS, int(for_dgrad),
-             stream())
+             ns, stream())
         return y
     wp = packed_weight(weight, w4, for_dgrad, ns)
     y = torch.empty((B, Co, H, W), dtype=F32, device=xp.device)
@@ -333,14 +358,14 @@ def _tile_stats_of(x, B, G, HW):
     return stats, T // G, T
 
 
-def conv_wgrad_planes(xp, dyp, B, Ci, H, W, Co, KS, up2, out=None, accumulate=False):
-    """Weight gradient from the pre-split planes of x and dy (bf16x3; transposing-LDS-read kernel)."""
+def conv_wgrad_planes(xp, dyp, B, Ci, H, W, Co, KS, up2, out=None, accumulate=False, ns=2):
+    """Weight gradient from the pre-split planes of x and dy (two-plane formats; transposing-LDS-read kernel)."""
     dw = out if out is not None else torch.empty((Co, Ci, KS, KS), dtype=F32, device=xp.device)
     nws = lib.itcv_conv2d_wgrad_bf16p_workspace(B, Ci, H, W, Co, KS)
     ws = _ws(nws, xp.device)
 
-    call("itcv_conv2d_wgrad_bf16p", ptr(xp), ptr(dyp), ptr(dw), B, Ci, H, W, Co, KS, int(up2), int(accumulate), ptr(ws),
-         nws, stream())
+    call("itcv_conv2d_wgrad_bf16p", ptr(xp), ptr(dyp), ptr(dw), B, Ci, H, W, Co, KS, int(up2), int(ns), int(accumulate),
+         ptr(ws), nws, stream())
     return dw
 
 
@@ -401,7 +426,7 @@ def conv_wgrad_raw(x, dy, B, Ci, H, W, Co, KS, up2, out=None, accumulate=False):
     nws = lib.itcv_conv2d_wgrad_workspace(B, Ci, H, W, Co, KS)
     ws = _ws(nws, x.device)
     ns = _NS[_CONV_MATH[0]]
-    if ns and lib.itcv_conv2d_wgrad_bf16s_supported(Ci, H, W, Co, KS):
+    if ns in (2, 3) and lib.itcv_conv2d_wgrad_bf16s_supported(Ci, H, W, Co, KS):
         if up2:   # the split kernel reads 8-pixel chunks: materialise the x2 nearest upsampling once
             xu = torch.empty((B, Ci, H, W), dtype=F32, device=x.device)
             call("itcv_upsample2_fwd", ptr(x), ptr(xu), B * Ci, H // 2, W // 2, stream())
@@ -448,11 +473,11 @@ def _tagged_planes(t, ns):
     return tag[0]
 
 
-def planes_of(t, ns):
-    """Planes of ``t``: the ones its producer attached, else a split pass."""
+def planes_of(t, ns, gradient=False):
+    """Planes of ``t``: the ones its producer attached, else a split pass (``gradient``: see split_planes)."""
     p = _tagged_planes(t, ns)
     PLANES_STATS[0 if p is not None else 1] += 1
-    return p if p is not None else split_planes(t, ns)
+    return p if p is not None else split_planes(t, ns, gradient)
 
 
 def conv_input_planes_ns(conv, up2=False):
@@ -469,10 +494,10 @@ def conv_grad_planes_ns(conv, needs_input_grad=True):
         return 0
     ks = conv.kernel_size[0]
     ns = _planes_ns(conv.out_channels, conv.in_channels, ks, False) if needs_input_grad else 0
-    if not ns and _NS[_CONV_MATH[0]] == 2 and _PLANES[0] and (ks == 3 or (ks == 5 and _SMALL_PLANES[0]
-                                                                       and conv.in_channels <= 3
-                                                                       and conv.out_channels == 64)):
-        ns = 2    # weight gradient on planes (shape support is re-checked where the planes are consumed)
+    if not ns and _two(_NS[_CONV_MATH[0]]) and _PLANES[0] and (ks == 3 or (ks == 5 and _SMALL_PLANES[0]
+                                                                           and conv.in_channels <= 3
+                                                                           and conv.out_channels == 64)):
+        ns = _NS[_CONV_MATH[0]]    # weight gradient on planes (shape support is re-checked where the planes are consumed)
     return ns
 
 
@@ -485,7 +510,7 @@ def conv_input_mode(conv, B, H, W, up2=False):
     ks = conv.kernel_size[0]
     wg_ok = (_wgrad_planes_ok(B, conv.in_channels, H, W, conv.out_channels, ks)
              or _wgrad5_mode(conv.in_channels, H, W, conv.out_channels, ks, up2) == "predict")
-    return ns, not (ns == 2 and wg_ok)
+    return ns, not (_two(ns) and wg_ok)
 
 
 def conv_grad_mode(conv, B, H, W, needs_input_grad=True):
@@ -495,7 +520,7 @@ def conv_grad_mode(conv, B, H, W, needs_input_grad=True):
         return 0, True
     ks = conv.kernel_size[0]
     dgrad_ok = (not needs_input_grad) or _planes_ns(conv.out_channels, conv.in_channels, ks, False) == ns
-    wgrad_ok = ns == 2 and _wgrad_planes_ok(B, conv.in_channels, H, W, conv.out_channels, ks)
+    wgrad_ok = _two(ns) and _wgrad_planes_ok(B, conv.in_channels, H, W, conv.out_channels, ks)
     return ns, not (dgrad_ok and wgrad_ok and conv.bias is None)
 
 
@@ -504,8 +529,8 @@ def _planes_ns(Ci, Co, KS, up2):
     ns = _NS[_CONV_MATH[0]]
     if not ns or not _PLANES[0]:
         return 0
-    if not up2 and ns == 2 and _SMALL_PLANES[0] and lib.itcv_conv2d_small_cout_bf16p_supported(Ci, Co, KS):
-        return 2    # the 5x5 predict conv / stem data-gradient on the matrix cores (bf16x3 only)
+    if not up2 and _two(ns) and _SMALL_PLANES[0] and lib.itcv_conv2d_small_cout_bf16p_supported(Ci, Co, KS):
+        return ns    # the 5x5 predict conv / stem data-gradient on the matrix cores (two-plane formats)
     if not up2 and (lib.itcv_conv2d_small_cout_supported(Co, KS) or lib.itcv_conv2d_small_cin_supported(Ci, KS)):
         return 0
     return ns if lib.itcv_conv2d_bf16s_supported(Ci, Co, KS) else 0
@@ -513,7 +538,7 @@ def _planes_ns(Ci, Co, KS, up2):
 
 def _wgrad5_mode(Ci, H, W, Co, KS, up2):
     """'stem' / 'predict' when the 5x5 weight gradient with a 3-channel side runs on the matrix cores (bf16x3)."""
-    if up2 or KS != 5 or _NS[_CONV_MATH[0]] != 2 or not (_PLANES[0] and _SMALL_PLANES[0]):
+    if up2 or KS != 5 or not _two(_NS[_CONV_MATH[0]]) or not (_PLANES[0] and _SMALL_PLANES[0]):
         return None
     if Ci <= 3 and lib.itcv_conv2d_wgrad5_bf16p_supported(Ci, Co, H, W):
         return "stem"
@@ -522,19 +547,21 @@ def _wgrad5_mode(Ci, H, W, Co, KS, up2):
     return None
 
 
-def conv_wgrad5_planes(small, big_planes, B, Cs, H, W, stem, out=None, accumulate=False):
-    """5x5 weight gradient with a <= 3-channel side from the planes of the 64-channel side."""
+def conv_wgrad5_planes(small, big_planes, B, Cs, H, W, stem, out=None, accumulate=False, ns=2):
+    """5x5 weight gradient with a <= 3-channel side from the planes of the 64-channel side.  fp16 form: the predict
+    conv's small side is a gradient tensor and gets a device-side scale; the stem's is the input image (scale 1)."""
     dw = out if out is not None else torch.empty((64, Cs, 5, 5) if stem else (Cs, 64, 5, 5), dtype=F32, device=small.device)
     nws = lib.itcv_conv2d_wgrad5_bf16p_workspace(B, H)
     ws = _ws(nws, small.device)
 
-    call("itcv_conv2d_wgrad5_bf16p", ptr(small), ptr(big_planes), ptr(dw), B, Cs, H, W, int(stem), int(accumulate), ptr(ws),
-         nws, stream())
+    amax = absmax_parts(small) if (ns == F16X2 and not stem) else None
+    call("itcv_conv2d_wgrad5_bf16p", ptr(small), ptr(big_planes), ptr(dw), B, Cs, H, W, int(stem), int(ns), ptr(amax),
+         int(accumulate), ptr(ws), nws, stream())
     return dw
 
 
 def _wgrad_planes_ok(B, Ci, H, W, Co, KS):
-    return bool(_NS[_CONV_MATH[0]] == 2 and _PLANES[0] and lib.itcv_conv2d_wgrad_bf16p_supported(B, Ci, H, W, Co, KS))
+    return bool(_two(_NS[_CONV_MATH[0]]) and _PLANES[0] and lib.itcv_conv2d_wgrad_bf16p_supported(B, Ci, H, W, Co, KS))
 
 
 class Conv2dFn(Function):
@@ -559,7 +586,7 @@ class Conv2dFn(Function):
         else:
             y = conv_apply(_require_fp32(x, "Conv2dFn.forward"), weight, weight, 0, b, B, Ci, H, W, Co, KS, up2)
         wg_planes = _wgrad_planes_ok(B, Ci, H, W, Co, KS)
-        keep_xp = xp if (ns == 2 and (wg_planes or _wgrad5_mode(Ci, H, W, Co, KS, up2) == "predict")) else None
+        keep_xp = xp if (_two(ns) and (wg_planes or _wgrad5_mode(Ci, H, W, Co, KS, up2) == "predict")) else None
         ctx.save_for_backward(None if keep_xp is not None else _require_fp32(x, "Conv2dFn.forward (saved input)"),
                               weight, bias, keep_xp)
         ctx.cfg = (B, Ci, H, W, Co, KS, up2, bias is not None, (Hs, Ws))
@@ -575,8 +602,9 @@ class Conv2dFn(Function):
         ns_d = _planes_ns(Co, Ci, KS, False) if ctx.needs_input_grad[0] else 0
         wg_planes = ctx.needs_input_grad[1] and _wgrad_planes_ok(B, Ci, H, W, Co, KS)
         dyp = None
+        fmt2 = F16X2 if _NS[_CONV_MATH[0]] == F16X2 else 2       # the two-plane format of the current mode
         if ns_d or wg_planes:
-            dyp = planes_of(dy, ns_d if ns_d else 2)
+            dyp = planes_of(dy, ns_d if ns_d else fmt2, gradient=True)
         if ctx.needs_input_grad[0]:
             if ns_d:
                 dx = conv_apply_planes(dyp, weight, weight, 1, None, B, Co, H, W, Ci, KS, False, ns_d)
@@ -592,23 +620,23 @@ class Conv2dFn(Function):
         if wg5 is not None:
             tgt = _grad_target(weight)
             if wg5 == "stem":
-                small, big = _require_fp32(x, "Conv2dFn.backward (5x5 weight gradient)"), (dyp if dyp is not None else planes_of(dy, 2))
+                small, big = _require_fp32(x, "Conv2dFn.backward (5x5 weight gradient)"), (dyp if dyp is not None else planes_of(dy, fmt2, gradient=True))
             else:
-                small, big = _require_fp32(dy, "Conv2dFn.backward (5x5 weight gradient)"), (xp if xp is not None else split_planes(x, 2))
+                small, big = _require_fp32(dy, "Conv2dFn.backward (5x5 weight gradient)"), (xp if xp is not None else split_planes(x, fmt2))
             cs = Ci if wg5 == "stem" else Co
             if tgt is not None:
-                conv_wgrad5_planes(small, big, B, cs, H, W, wg5 == "stem", out=tgt, accumulate=True)
+                conv_wgrad5_planes(small, big, B, cs, H, W, wg5 == "stem", out=tgt, accumulate=True, ns=fmt2)
             else:
-                dw = conv_wgrad5_planes(small, big, B, cs, H, W, wg5 == "stem")
+                dw = conv_wgrad5_planes(small, big, B, cs, H, W, wg5 == "stem", ns=fmt2)
         elif ctx.needs_input_grad[1]:
             tgt = _grad_target(weight)
-            if wg_planes and (ns_d in (0, 2)):
+            if wg_planes and (ns_d in (0, fmt2)):
                 if xp is None:
-                    xp = split_planes(x, 2)
+                    xp = split_planes(x, fmt2)
                 if tgt is not None:
-                    conv_wgrad_planes(xp, dyp, B, Ci, H, W, Co, KS, up2, out=tgt, accumulate=True)
+                    conv_wgrad_planes(xp, dyp, B, Ci, H, W, Co, KS, up2, out=tgt, accumulate=True, ns=fmt2)
                 else:
-                    dw = conv_wgrad_planes(xp, dyp, B, Ci, H, W, Co, KS, up2)
+                    dw = conv_wgrad_planes(xp, dyp, B, Ci, H, W, Co, KS, up2, ns=fmt2)
             else:
                 if x is None:
                     raise abi.HipExtensionError("Conv2dFn.backward: conv math mode changed between forward and backward")
@@ -692,6 +720,12 @@ class BnActFn(Function):
         oshape = (B, C, H // 2, W // 2) if pool else (B, C, H, W)
         y = torch.empty(oshape, dtype=F32, device=dev)
         yp, pstride = None, 0
+        if F16X2 in (out_planes, grad_planes) and not (training and world == 1):
+            # fp16 planes carry one scale record per tensor, written by the single-call training forms (itcv_bn_train_fwd /
+            # _bwd); the per-group eval / Sync-BN calls below hand the consumers fp32 tensors instead (split on demand)
+            out_planes = 0 if out_planes == F16X2 else out_planes
+            grad_planes = 0 if grad_planes == F16X2 else grad_planes
+            out_fp32 = grad_fp32 = True
         if out_planes and lib.itcv_bn_act_planes_supported(C, H, W, int(pool)):
             yp = torch.empty(lib.itcv_planes_bytes(B, C, oshape[2] * oshape[3], out_planes) // 4, dtype=torch.int32,
                              device=dev)

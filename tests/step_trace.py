@@ -103,6 +103,8 @@ STEP_TOL = {
     "fp32": dict(E=dict(img=1e-4, enc=1e-4, hook=1e-4), ratio=dict(Egrad=1.5, img=1.5, enc=1.5, hook=1.5, Dgrad=1.5), dec=1e-4),
     "bf16x6": dict(E=dict(img=1e-4, enc=1e-4, hook=1e-4), ratio=dict(Egrad=1.5, img=1.5, enc=1.5, hook=1.5, Dgrad=1.5), dec=1e-4),
     "bf16x3": dict(E=dict(img=1e-4, enc=1e-4, hook=1e-4), ratio=dict(Egrad=5.0, img=20.0, enc=12.0, hook=8.0, Dgrad=3.0), dec=1e-4),
+    # two fp16 planes with a power-of-two scale, 3 products: held to the SAME bar as exact fp32 (as accurate as the reference's CPU path)
+    "f16x3": dict(E=dict(img=1e-4, enc=1e-4, hook=1e-4), ratio=dict(Egrad=1.5, img=1.5, enc=1.5, hook=1.5, Dgrad=1.5), dec=1e-4),
 }
 FLOOR = 1e-4
 PHASES = dict(E=dict(decoded=slice(0, 4), encoded=slice(0, 3), kl=slice(0, 3), rec=slice(0, 3), grads=0, part="encoder"),

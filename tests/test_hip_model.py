@@ -167,7 +167,7 @@ class _DS:
         return self.n
 
 
-MATH_MODES = ["fp32", "bf16x6", "bf16x3"]
+MATH_MODES = ["fp32", "bf16x6", "bf16x3", "f16x3"]
 
 
 def make_solver(name, model, hp, loss_type="mse", math="fp32"):

@@ -164,6 +164,167 @@ def test_batched_bn_act_conv_chain_vs_fp64(HF):
     assert rel_err(y[sel], F.conv2d(act[sel], w.double(), padding=1)) < 5e-5
 
 
+WGRAD_CASES_F16 = [(2, 64, 16, 16, 64, False), (4, 128, 4, 4, 256, False), (2, 32, 32, 32, 48, False), (1, 64, 64, 64, 64, False),
+                   (2, 128, 16, 16, 64, True), (2, 512, 8, 8, 256, False), (1, 64, 8, 128, 64, False), (3, 64, 64, 64, 64, True)]
+
+
+# ---- fp16 planes ("f16x3": hi / lo fp16 planes of S * x, 3 products) ---------------------------------------------------
+def unpack_f16_planes(xp, shape):
+    """fp16 planes [2][B][C/8][H*W] x 8 fp16 + scale record -> (fp32 [B,C,H,W] = (hi + lo) / S, S)."""
+    B, C, H, W = shape
+    n = 2 * B * (C // 8) * H * W * 4                                        # int32 words of the two planes
+    rec = xp[n:n + 4].view(torch.float32)
+    scale, inv = float(rec[0]), float(rec[1])
+    assert scale > 0 and scale * inv == 1.0 and float(torch.tensor(scale).log2()) % 1 == 0     # an exact power of two
+    vals = xp[:n].view(torch.float16).view(2, B, C // 8, H * W, 8).float()
+    return (vals.sum(0) * inv).permute(0, 1, 3, 2).reshape(B, C, H, W), scale
+
+
+@pytest.mark.parametrize("magnitude", [1.0, 3e-9, 2e5])
+def test_f16_planes_reconstruct(HF, magnitude):
+    """Two fp16 planes carry 22 significand bits of S*x: a gradient-like tensor of ANY magnitude (1e-9 .. 1e5, heavy
+    tailed) comes back to 2^-20.5 of each element (elements >= 2^-18 of the largest) and 2^-38 of the largest below that;
+    the scale is the power of two that puts the largest element in [2^14, 2^15).  Activations (scale 1) alike."""
+    g = torch.Generator().manual_seed(11)
+    x = (torch.randn(3, 16, 8, 12, generator=g) * torch.logspace(-2, 0, 16).view(1, 16, 1, 1) * magnitude).to(dev())
+    xp = HF.split_planes(x, HF.F16X2, gradient=True)
+    back, scale = unpack_f16_planes(xp, x.shape)
+    top = float(x.abs().max())
+    assert 2.0 ** 14 <= top * scale < 2.0 ** 15
+    err = (back - x).abs()
+    big = x.abs() >= top * 2.0 ** -18
+    assert float((err[big] / x.abs()[big]).max()) < 2.0 ** -20.5
+    if (~big).any():
+        assert float(err[~big].max()) < top * 2.0 ** -38
+    if magnitude == 1.0:
+        back1, s1 = unpack_f16_planes(HF.split_planes(x, HF.F16X2), x.shape)
+        assert s1 == 1.0 and float(((back1 - x).abs() / x.abs().clamp_min(2.0 ** -3)).max()) < 2.0 ** -20.5
+
+
+@pytest.mark.parametrize("case", PLANES_CASES[:7] + PLANES_CASES[7:9] + PERSIST_CASES[:2])
+def test_f16_planes_conv_vs_fp64(HF, case):
+    """Forward and data-gradient on fp16 planes (band, persistent band, 128-pixel kernels): within 1.5e-6 of the result
+    scale of an fp64 convolution -- the level of the exact-fp32 MFMA kernel (fp32 accumulation), 30x below bf16x3 -- with
+    the data-gradient's input at gradient-like magnitude (1e-7)."""
+    B, Ci, H, W, Co, up2 = case
+    B = min(B, 6)
+    g = torch.Generator().manual_seed(sum(case[:5]))
+    hs, ws = (H // 2, W // 2) if up2 else (H, W)
+    x = torch.randn(B, Ci, hs, ws, generator=g)
+    w = torch.randn(Co, Ci, 3, 3, generator=g) / (Ci * 9) ** 0.5
+    dy = torch.randn(B, Co, H, W, generator=g) * 1e-7
+    xd, wd, dyd = x.to(dev()), w.to(dev()), dy.to(dev())
+    xin = F.interpolate(x.double(), scale_factor=2, mode="nearest") if up2 else x.double()
+    ref = F.conv2d(xin, w.double(), padding=1)
+    refd = F.conv_transpose2d(dy.double(), w.double(), padding=1)
+    with HF.conv_math_scope("f16x3"):
+        y = HF.conv_apply_planes(HF.split_planes(xd, 4), wd, wd, 0, None, B, Ci, H, W, Co, 3, up2, 4)
+        dx = None
+        if HF.lib.itcv_conv2d_bf16s_supported(Co, Ci, 3):   # data-gradient: the channel roles swap
+            dx = HF.conv_apply_planes(HF.split_planes(dyd, 4, gradient=True), wd, wd, 1, None, B, Co, H, W, Ci, 3, False, 4)
+    with HF.conv_math_scope("fp32"):
+        y32 = HF.conv_apply(xd, wd, wd, 0, None, B, Ci, H, W, Co, 3, up2)
+    e16, e32 = rel_err(y, ref), rel_err(y32, ref)
+    assert e16 < 1.5e-6 and e16 < 3 * e32 + 2e-7, (e16, e32)
+    assert dx is None or rel_err(dx, refd) < 1.5e-6
+
+
+@pytest.mark.parametrize("case", WGRAD_CASES_F16)
+def test_f16_planes_weight_gradient(HF, case):
+    """Weight gradient from fp16 planes (x at O(1), dy at 1e-8): 1.5e-6 of the result scale vs fp64, bitwise repeatable."""
+    B, Ci, H, W, Co, up2 = case
+    g = torch.Generator().manual_seed(7 + sum(case[:5]))
+    hs, ws = (H // 2, W // 2) if up2 else (H, W)
+    x = torch.randn(B, Ci, hs, ws, generator=g)
+    dy = torch.randn(B, Co, H, W, generator=g) * 1e-8
+    xin = F.interpolate(x.double(), scale_factor=2, mode="nearest") if up2 else x.double()
+    ref = torch.nn.grad.conv2d_weight(xin, (Co, Ci, 3, 3), dy.double(), padding=1)
+    xp, dyp = HF.split_planes(x.to(dev()), 4), HF.split_planes(dy.to(dev()), 4, gradient=True)
+    dw = HF.conv_wgrad_planes(xp, dyp, B, Ci, H, W, Co, 3, up2, ns=4)
+    assert rel_err(dw, ref) < 1.5e-6
+    assert torch.equal(dw, HF.conv_wgrad_planes(xp, dyp, B, Ci, H, W, Co, 3, up2, ns=4))
+
+
+@pytest.mark.parametrize("shape,pool,groups", [((4, 64, 32, 32), False, 1), ((4, 64, 32, 32), True, 2), ((8, 128, 16, 16), False, 2),
+                                               ((16, 512, 4, 4), False, 2), ((2, 16, 8, 8), False, 1)])
+@pytest.mark.parametrize("gscale", [1.0, 1e-9])
+def test_batchnorm_emits_f16_planes(HF, shape, pool, groups, gscale):
+    """BnActFn with fp16 planes: the forward planes reconstruct y (scale 1); the backward planes reconstruct dx with the
+    scale the apply pass derives from the partial pass's maxima -- a power of two, with max|dx| * S below 2^15 (never
+    overflowing) and above 2^2 (bound loose by at most 2^13: typical values keep all 22 bits) -- in every launch form
+    (sliced / one block per channel, one or two BatchNorm groups), at O(1) and at 1e-9 gradient magnitude."""
+    B, C, H, W = shape
+    g = torch.Generator().manual_seed(B + C + H + groups)
+    x = torch.randn(B, C, H, W, generator=g) * 1.5 + 0.3
+    gamma, beta = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g)
+    oshape = (B, C, H // 2, W // 2) if pool else shape
+    dy = torch.randn(*oshape, generator=g) * gscale
+    d = dev()
+    rm, rv = torch.zeros(C, device=d), torch.ones(C, device=d)
+    nbt = torch.zeros((), dtype=torch.int64, device=d)
+    xd = x.to(d).requires_grad_(True)
+    seen = []
+
+    class Tap(torch.autograd.Function):      # hands the gradient OBJECT BnActFn returns (with its planes tag) to the test
+        @staticmethod
+        def forward(ctx, t):
+            return t.view_as(t)
+
+        @staticmethod
+        def backward(ctx, g):
+            seen.append(g)
+            return g
+
+    y = HF.BnActFn.apply(Tap.apply(xd), gamma.to(d), beta.to(d), None, rm, rv, nbt, 1e-4, 0.1, 0.2, pool, True, None, 4, 4, True, True,
+                         groups)
+    yp = HF._tagged_planes(y, 4)
+    assert yp is not None
+    back, s = unpack_f16_planes(yp, y.shape)
+    assert s == 1.0 and float((back - y.detach()).abs().max()) < 2.0 ** -21 * float(y.detach().abs().max())
+    y.backward(dy.to(d))
+    dx = seen[0]
+    dxp = HF._tagged_planes(dx, 4)
+    assert dxp is not None and torch.equal(dx, xd.grad)
+    backd, sd = unpack_f16_planes(dxp, dx.shape)
+    top = float(dx.abs().max())
+    assert 2.0 ** 2 < top * sd < 2.0 ** 15, (top * sd, sd)
+    assert float((backd - dx).abs().max()) < top * 2.0 ** -21
+    # same values as the bf16-planes form computes for dx (the fp32 tensor does not depend on the plane format)
+    xd2 = x.to(d).requires_grad_(True)
+    y2 = HF.BnActFn.apply(xd2, gamma.to(d), beta.to(d), None, rm.clone(), rv.clone(), nbt.clone(), 1e-4, 0.1, 0.2, pool, True,
+                          None, 2, 2, True, True, groups)
+    y2.backward(dy.to(d))
+    assert torch.equal(y2, y) and torch.equal(xd2.grad, dx)
+
+
+def test_f16_small_layer_kernels_vs_fp64(HF):
+    """The 5x5 stem / predict layers in fp16 planes form: 3 -> 64 forward and data-gradient (in-register split, gradient
+    input at 1e-8), 64 -> 3 on planes, and both 5x5 weight gradients -- 2e-6 of the result scale vs fp64."""
+    g = torch.Generator().manual_seed(9)
+    B, S = 3, 64
+    d = dev()
+    img = torch.rand(B, 3, S, S, generator=g)
+    w_stem = torch.randn(64, 3, 5, 5, generator=g) / 6.0
+    w_pred = torch.randn(3, 64, 5, 5, generator=g) / 40.0
+    bias = torch.randn(3, generator=g)
+    act = torch.randn(B, 64, S, S, generator=g)
+    gsmall = torch.randn(B, 3, S, S, generator=g) * 1e-8
+    gbig = torch.randn(B, 64, S, S, generator=g) * 1e-8
+    with HF.conv_math_scope("f16x3"):
+        y = HF.conv_apply(img.to(d), w_stem.to(d), w_stem.to(d), 0, None, B, 3, S, S, 64, 5, False)
+        assert rel_err(y, F.conv2d(img.double(), w_stem.double(), padding=2)) < 2e-6
+        dxp = HF.conv_apply(gsmall.to(d), w_pred.to(d), w_pred.to(d), 1, None, B, 3, S, S, 64, 5, False)
+        assert rel_err(dxp, F.conv_transpose2d(gsmall.double(), w_pred.double(), padding=2)) < 2e-6
+        yp = HF.conv_apply_planes(HF.split_planes(act.to(d), 4), w_pred.to(d), w_pred.to(d), 0, bias.to(d), B, 64, S, S, 3, 5, False, 4)
+        assert rel_err(yp, F.conv2d(act.double(), w_pred.double(), bias.double(), padding=2)) < 2e-6
+        dxs = HF.conv_apply_planes(HF.split_planes(gbig.to(d), 4, gradient=True), w_stem.to(d), w_stem.to(d), 1, None, B, 64, S, S, 3, 5, False, 4)
+        assert rel_err(dxs, F.conv_transpose2d(gbig.double(), w_stem.double(), padding=2)) < 2e-6
+        dw_stem = HF.conv_wgrad5_planes(img.to(d), HF.split_planes(gbig.to(d), 4, gradient=True), B, 3, S, S, True, ns=4)
+        assert rel_err(dw_stem, torch.nn.grad.conv2d_weight(img.double(), (64, 3, 5, 5), gbig.double(), padding=2)) < 2e-6
+        dw_pred = HF.conv_wgrad5_planes(gsmall.to(d), HF.split_planes(act.to(d), 4), B, 3, S, S, False, ns=4)
+        assert rel_err(dw_pred, torch.nn.grad.conv2d_weight(act.double(), (3, 64, 5, 5), gsmall.double(), padding=2)) < 2e-6
+
+
 WGRAD_CASES = [  # B, Ci, H, W, Co, up2
     (2, 64, 16, 16, 64, False), (4, 128, 4, 4, 256, False), (2, 32, 32, 32, 48, False), (1, 64, 64, 64, 64, False),
     (2, 128, 16, 16, 64, True), (2, 512, 8, 8, 256, False), (8, 24, 8, 8, 136, False),
