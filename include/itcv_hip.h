@@ -373,6 +373,9 @@ int itcv_adam_step(float* p, const float* g, float* m, float* v, size_t n, float
 int itcv_adam_step_dev(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1,
                        float beta2, float eps, int* step_dev, void* stream);
 int itcv_fill(float* x, size_t n, float value, void* stream);
+/* Input pipeline (dataset.py:219-224 transforms.RandomHorizontalFlip, moved behind the host -> device copy):
+ * y[b] = x[b] mirrored along W where flip[b] != 0, else x[b]; x, y are [B][rows_per_image][W] (rows = C*H), x != y. */
+int itcv_hflip(const float* x, float* y, const unsigned char* flip, int B, int rows_per_image, int W, void* stream);
 
 #ifdef __cplusplus
 }

@@ -144,6 +144,16 @@ __global__ void adam_dev_kernel(float* __restrict__ p, const float* __restrict__
 }
 __global__ void bump_step_kernel(int* step_dev) { step_dev[0] += 1; }
 
+// transforms.RandomHorizontalFlip on the device (dataset.py:219-224): image b is mirrored along W where flip[b] != 0
+__global__ void hflip_kernel(const float* __restrict__ x, float* __restrict__ y, const unsigned char* __restrict__ flip,
+                             size_t rows_per_image, int W, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t row = i / W;
+    const int w = (int)(i - row * W);
+    y[i] = flip[row / rows_per_image] ? x[row * W + (W - 1 - w)] : x[i];
+  }
+}
+
 __global__ void fill_kernel(float* __restrict__ x, size_t n, float value) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
     x[i] = value;
@@ -260,6 +270,14 @@ int itcv_adam_step_dev(float* p, const float* g, float* m, float* v, size_t n, f
   ITCV_CHECK_LAUNCH("itcv_adam_step_dev");
   hipLaunchKernelGGL(bump_step_kernel, dim3(1), dim3(1), 0, S(stream), step_dev);
   ITCV_CHECK_LAUNCH("itcv_adam_step_dev(bump)");
+  return 0;
+}
+
+int itcv_hflip(const float* x, float* y, const unsigned char* flip, int B, int rows_per_image, int W, void* stream) {
+  ITCV_REQUIRE(x && y && flip && x != y && B > 0 && rows_per_image > 0 && W > 0, "itcv_hflip");
+  const size_t n = (size_t)B * rows_per_image * W;
+  hipLaunchKernelGGL(hflip_kernel, dim3(stream_grid(n, 1)), dim3(256), 0, S(stream), x, y, flip, (size_t)rows_per_image, W, n);
+  ITCV_CHECK_LAUNCH("itcv_hflip");
   return 0;
 }
 

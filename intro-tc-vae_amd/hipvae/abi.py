@@ -128,6 +128,7 @@ SIGNATURES = {
     "itcv_adam_step": (i32, [p, p, p, p, sz, f32, f32, f32, f32, i32, p]),
     "itcv_adam_step_dev": (i32, [p, p, p, p, sz, f32, f32, f32, f32, p, p]),
     "itcv_fill": (i32, [p, sz, f32, p]),
+    "itcv_hflip": (i32, [p, p, p, i32, i32, i32, p]),
 }
 
 TC_VAR_FROM_ROW, TC_EPS_DENSITY, TC_WEIGHTED = 1, 2, 4

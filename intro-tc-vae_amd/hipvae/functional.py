@@ -203,16 +203,22 @@ class _PackGroup:
             self.tables.pop(k, None)
             _pack_entry(weight, _pack_key(weight))[1][k] = wp
             return wp
+        # The table holds every member's raw source pointer: before a grouped launch each member must still be alive and
+        # sit where it was registered (a `p.data` reassignment or a freed weight would be re-packed from stale memory).
+        # Members that moved or died leave the group (and drop the table); they re-join on their next own request.
+        stale = [i for i, r in mem.items()
+                 if r[0]() is None or r[0]().data_ptr() != r[2] or tuple(r[0]().shape[:3]) != r[1]]
+        if stale:
+            for i in stale:
+                del mem[i]
+            self.tables.pop(k, None)
         tab = self.tables.get(k)
         if tab is None:
-            for i in [i for i, r in mem.items() if r[0]() is None]:
-                del mem[i]
             tab = self.tables[k] = self._build(mem, for_dgrad, ns, weight.device)
         call("itcv_conv2d_pack_weights_bf16s", ptr(tab[0]), tab[1], tab[2], ns, stream())
-        for r in mem.values():
+        for r in mem.values():        # every remaining member was just verified: its buffer holds the fresh packing
             m = r[0]()
-            if m is not None:
-                _pack_entry(m, _pack_key(m))[1][k] = r[3]
+            _pack_entry(m, _pack_key(m))[1][k] = r[3]
         return rec[3]
 
     @staticmethod

@@ -17,6 +17,11 @@ Same surface as the reference class: ``PrefetchLoader(data_loader, pre_process)`
 ``.to(device)`` calls to be no-ops).  Everything that is not a tensor passes through untouched.  A slot of the ring is
 reused only after the consumer has come back for the batch after it, i.e. after all work on that batch has been issued
 to the compute stream (the reuse then waits for that work on the device): consume each batch within its iteration.
+
+``flip_p`` > 0 moves the reference's only augmentation, ``transforms.RandomHorizontalFlip(p)`` (dataset.py:219-224, run
+per sample by a PIL worker there), behind the copy: every 4-D float image batch is mirrored per sample with probability
+``flip_p`` by one HIP kernel on the side stream (``itcv_hflip``; the coin flips come from a device generator seeded with
+``flip_seed``).  The wrapped dataset then skips its own flip and the PIL workers only decode and resize.
 """
 import ctypes
 import queue
@@ -34,10 +39,10 @@ def _host_copy(dst, src):
 
 
 class _Slot:
-    __slots__ = ("host", "dev", "ready", "free", "used")
+    __slots__ = ("host", "dev", "aug", "ready", "free", "used")
 
     def __init__(self):
-        self.host, self.dev = [], []
+        self.host, self.dev, self.aug = [], [], []
         self.ready, self.free, self.used = torch.cuda.Event(), torch.cuda.Event(), False
 
 
@@ -46,7 +51,7 @@ class _Stop(Exception):
 
 
 class PrefetchLoader:
-    def __init__(self, data_loader, pre_process=None, device=None, depth=3):
+    def __init__(self, data_loader, pre_process=None, device=None, depth=3, flip_p=0.0, flip_seed=0):
         """``depth``: ring slots (>= 2): one being consumed, the others landed or in flight ahead of it."""
         if depth < 2:
             raise ValueError("depth must be >= 2")
@@ -56,6 +61,9 @@ class PrefetchLoader:
         if self.device.type != "cuda":
             raise ValueError("PrefetchLoader feeds a HIP device; use the reference's WrappedDataLoader on the CPU")
         self.depth = depth
+        self.flip_p = float(flip_p)
+        self._flip_gen = None
+        self._flip_seed = int(flip_seed)
         self._stream = None
         self._slots = None
 
@@ -85,11 +93,31 @@ class PrefetchLoader:
             _host_copy(slot.host[ti], it)       # pageable -> pinned (the DataLoader's tensors are pageable)
             with torch.cuda.stream(side):
                 slot.dev[ti].copy_(slot.host[ti], non_blocking=True)
-            out.append(slot.dev[ti])
+                staged = slot.dev[ti]
+                if self.flip_p > 0.0 and it.dim() == 4 and it.dtype == torch.float32:
+                    staged = self._flip(slot, ti, staged, side)
+            out.append(staged)
             ti += 1
         slot.ready.record(side)
         slot.used = True
         return out if isinstance(batch, (tuple, list)) else out[0]
+
+    def _flip(self, slot, ti, x, side):
+        """RandomHorizontalFlip(p) of an image batch on the side stream (already current): per-sample coin flips from the
+        device generator, one kernel into the slot's second device buffer."""
+        from . import abi
+        if self._flip_gen is None:
+            self._flip_gen = torch.Generator(device=self.device)
+            self._flip_gen.manual_seed(self._flip_seed)
+        while len(slot.aug) <= ti:
+            slot.aug.append(None)
+        if slot.aug[ti] is None or slot.aug[ti].shape != x.shape:
+            slot.aug[ti] = torch.empty_like(x)
+        B, C, H, W = x.shape
+        coins = (torch.rand(B, device=self.device, generator=self._flip_gen) < self.flip_p).to(torch.uint8)
+        abi.call("itcv_hflip", abi.ptr(x), abi.ptr(slot.aug[ti]), coins.data_ptr(), B, C * H, W, side.cuda_stream)
+        coins.record_stream(side)
+        return slot.aug[ti]
 
     def _producer(self, q, credits, stop):
         try:
@@ -111,12 +139,18 @@ class PrefetchLoader:
             q.put(e)
 
     def __iter__(self):
+        # one producer at a time: an iteration abandoned early (break / exception) has stopped its producer in `finally`
+        # below (joined without a timeout); a second iterator started WHILE one is still live would share the ring
+        old = getattr(self, "_thread", None)
+        if old is not None and old.is_alive():
+            raise RuntimeError("PrefetchLoader: the previous iteration is still running (one iterator at a time)")
         if self._stream is None:
             with torch.cuda.device(self.device):
                 self._stream = torch.cuda.Stream(device=self.device)
-                self._slots = [_Slot() for _ in range(self.depth)]
+        # a fresh ring per iteration: no slot state (used flags, events) survives an abandoned epoch
+        self._slots = [_Slot() for _ in range(self.depth)]
         q, credits, stop = queue.Queue(), threading.Semaphore(self.depth), threading.Event()
-        th = threading.Thread(target=self._producer, args=(q, credits, stop), daemon=True, name="itcv-prefetch")
+        th = self._thread = threading.Thread(target=self._producer, args=(q, credits, stop), daemon=True, name="itcv-prefetch")
         th.start()
         prev = None
         try:
@@ -146,4 +180,7 @@ class PrefetchLoader:
             stop.set()
             if prev is not None:
                 prev.free.record(torch.cuda.current_stream(self.device))
-            th.join(timeout=5.0)
+            # the producer polls `stop` every 0.1 s while it waits for a slot and checks it after every batch of the wrapped
+            # loader: it ends on its own; wait for it (a producer still inside the wrapped loader must not outlive this iterator)
+            th.join()
+            torch.cuda.current_stream(self.device).wait_stream(self._stream)   # copies still in flight land before the ring is dropped

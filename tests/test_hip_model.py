@@ -581,6 +581,41 @@ def test_prefetch_loader_equals_direct_feeding(graph):
     assert torch.equal(got, torch.cat([images, images]))
 
 
+def test_prefetch_loader_flips_on_the_gpu_and_survives_an_abandoned_epoch():
+    """SURVEY 8(f3), second half: transforms.RandomHorizontalFlip(p=0.5) (/root/reference/dataset.py:219-224) applied per
+    sample on the device behind the H2D copy: every delivered image is its source or the exact mirror of it, about half
+    are mirrored, labels pass untouched, the coin flips are reproducible from ``flip_seed``; an epoch abandoned by
+    ``break`` leaves no producer behind and the next epoch delivers every sample once, in order."""
+    from torch.utils.data import DataLoader, TensorDataset
+    from hipvae.loader import PrefetchLoader
+    g = torch.Generator().manual_seed(5)
+    images, labels = torch.rand(200, 3, 16, 32, generator=g), torch.arange(200)
+    dl = DataLoader(TensorDataset(images, labels), batch_size=25, shuffle=False)
+
+    def run(seed):
+        xs, ys = [], []
+        for x, y in PrefetchLoader(dl, None, flip_p=0.5, flip_seed=seed):
+            xs.append(x.cpu()), ys.append(y.cpu())
+        return torch.cat(xs), torch.cat(ys)
+
+    x1, y1 = run(7)
+    assert torch.equal(y1, labels)
+    same = (x1 == images).flatten(1).all(1)
+    mirrored = (x1 == images.flip(3)).flatten(1).all(1)
+    assert bool((same | mirrored).all()) and 60 < int(mirrored.sum()) < 140
+    x2, _ = run(7)
+    x3, _ = run(8)
+    assert torch.equal(x1, x2) and not torch.equal(x1, x3)
+    # abandon an epoch early, then iterate again
+    loader = PrefetchLoader(dl, None, depth=2)
+    for i, (x, y) in enumerate(loader):
+        if i == 2:
+            break
+    assert not loader._thread.is_alive()
+    got = torch.cat([b[1].cpu() for b in loader])
+    assert torch.equal(got, labels)
+
+
 @pytest.mark.parametrize("arch", ["conv", "res", "inception"])
 def test_bn_groups_model_pass_equals_separate_passes(arch):
     """models.bn_groups(2): one forward of two stacked batches == two forwards (outputs, running buffers, parameter
