@@ -11,9 +11,9 @@ Workloads (BASELINE.json configs; conv architecture, Adam lr 2e-4, clip 100, N =
                   with --gpus 8 this is BASELINE configs[3] (c4: global batch 512)
     c3            128x128x3, z=256, channels (64,128,256,512,512),     128 images per GPU
     c5            256x256x3, z=512, channels (64,128,256,512,512,512), 32 images per GPU  (--gpus 8: global batch 256)
-fp32 tensors throughout; the conv products run in the mode --math selects (default bf16x3 = what the reference's
-use_amp=True config maps to).  At N=1 on c2 the line also carries "modes": the same measurement in exact fp32 (the
-reference's own precision) and bf16x6, made in the same process.
+fp32 tensors throughout; the conv products run in the mode --math selects (default f16x3 = what the reference's
+use_amp=True config maps to: fp32-class accuracy on the fp16 matrix cores).  At N=1 on c2 the line also carries
+"modes": the same measurement in exact fp32 (the reference's own precision), bf16x3 and bf16x6, made in the same process.
 
 One process per GPU; N>1 shards the batch (weak scaling) with a flat RCCL all-reduce of the trained half's gradients
 per phase and an all-gather of mu for the full-batch TC estimator; BatchNorm statistics are per rank (throughput
@@ -30,7 +30,7 @@ dies with its own non-zero status and the supervisor prints the eager line with 
 Extra objects on the line:
   roofline      dominant kernel (an implicit-GEMM conv on the matrix cores): algorithmic FLOP of its launches / their
                 HIP-event durations, measured live on the launch stream; peak = dense MFMA peak of the arithmetic
-                (2500/3 TFLOP/s for bf16x3, 2500/6 for bf16x6, 157.3 for fp32; MI355X_MICROARCH.md); traffic = HBM
+                (2500/3 TFLOP/s for f16x3 and bf16x3, 2500/6 for bf16x6, 157.3 for fp32; MI355X_MICROARCH.md); traffic = HBM
                 bytes per launch from the committed rocprofv3 --pmc passes, only while the kernel sources are unchanged.
   cpu_baseline  the CPU oracle (oracle/, a PyTorch-CPU port pinned to the reference by golden vectors) timed on the
                 host cores: 1 warm-up + 3 timed steps (BASELINE.md protocol) on a bounded batch of the same workload.
@@ -165,7 +165,7 @@ def roofline_of(records, math, steps, eager_elapsed, where):
     conv_flop = sum(b[1] for b in buckets.values())
     dom_label, dom = max(buckets.items(), key=lambda kv: kv[1][2])
     achieved = dom[1] / dom[2] * 1e-12
-    if "bf16s" in dom_label or "bf16p" in dom_label:
+    if "bf16s" in dom_label or "bf16p" in dom_label or "planes" in dom_label or "mfma" in dom_label:
         products = 6 if "NS=3" in dom_label else 3
         kind = "fp16" if "NS=4" in dom_label else "bf16"
         peak, peak_note = PEAK_BF16_MFMA_TFLOPS / products, f"2500 TFLOP/s dense {kind} MFMA / {products} {kind} products per fp32 product"
@@ -300,9 +300,10 @@ def main():
                     help="N=1, c2: skip the additional fp32 / bf16x6 measurements (the 'modes' object)")
     ap.add_argument("--sync-bn", action="store_true",
                     help="N>1: all-reduce BatchNorm moments (full-batch parity mode); default is per-rank statistics")
-    ap.add_argument("--math", choices=["bf16x3", "bf16x6", "fp32", "f16x3"], default="bf16x3",
-                    help="conv GEMM arithmetic: bf16x3 = use_amp=True (the reference's config default), split-bf16 "
-                         "MFMA with fp32 accumulate; bf16x6 = fp32-class 3-way split; fp32 = exact fp32 MFMA")
+    ap.add_argument("--math", choices=["f16x3", "bf16x3", "bf16x6", "fp32"], default="f16x3",
+                    help="conv GEMM arithmetic: f16x3 = use_amp=True (the reference's config default): two scaled fp16 "
+                         "planes, 3 MFMA products, fp32 accumulate, fp32-class accuracy; bf16x3 = two bf16 planes "
+                         "(2^-16 per product); bf16x6 = three bf16 planes, 6 products; fp32 = exact fp32 MFMA")
     ap.add_argument("--no-graph", action="store_true", help="time eager launches instead of hipGraph replays (N=1)")
     ap.add_argument("--leg", choices=["eager", "graph"], default=None,
                     help="(internal, N>1) run ONE leg of the data-parallel measurement in this process; without it an N>1 "
@@ -393,7 +394,7 @@ def main():
         del solver, batches, m
         torch.cuda.empty_cache()
         out["modes"] = {}
-        for math in ("fp32", "bf16x6"):
+        for math in ("fp32", "bf16x3", "bf16x6"):
             if math == args.math:
                 continue
             mm = measure(wl, math, dev, args, rank, world, sync, use_graph, ddp_on)

@@ -43,7 +43,8 @@ int itcv_get_option(const char* name);
  * _end every conv entry point records a HIP event pair on its launch stream around its MAIN kernel
  * (not the split-K reduce).  _end waits for the events and returns the record count; record i is
  * (code = kind | KS<<4 | BM<<8 | up2<<16 | NS<<20 with kind 0 fwd fp32, 1 fwd split-bf16, 2 wgrad fp32,
- * 3 wgrad split-bf16, 4 small-Cout direct, 5 small-Cin direct, 6 fwd on planes, 7 wgrad on planes and 8 band-form fwd on planes -- for 7 and 8 the KS field holds log2(W);
+ * 3 wgrad split-bf16, 4 small-Cout direct, 5 small-Cin direct, 6 fwd on planes, 7 wgrad on planes, 8 / 9 band-form fwd on planes (one tile / persistent) -- for 7..9 the KS field
+ * holds log2(W) -- 10 small-Cout on planes, 11 small-Cin on the matrix cores, 12 5x5 weight gradient on planes (BM field = narrow side's channels);
  * algorithmic FLOP; elapsed ms). */
 int itcv_profile_begin(void);
 int itcv_profile_end(void);

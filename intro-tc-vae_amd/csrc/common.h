@@ -174,6 +174,12 @@ __device__ __forceinline__ mm_f32x16 mma32x32x16(bf16x8 a, bf16x8 b, mm_f32x16 c
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
 
+// 1/S of a scale record as a wave-uniform value in a scalar register: loaded ONCE where this is called (left as a plain
+// load the compiler re-issues it next to every use when it cannot prove that the epilogue's stores do not alias it)
+__device__ __forceinline__ float inv_scale_of(const ScaleRec* r) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, r->inv)));
+}
+
 // max of n non-negative floats at p, by one wave (all 64 lanes call; result in every lane)
 __device__ __forceinline__ float wave_absmax_of(const float* __restrict__ p, int n) {
   float m = 0.f;

@@ -142,7 +142,7 @@ __global__ __launch_bounds__(768) void conv_fwd_bf16p2_kernel(ConvArgsP2 a) {
   typedef BandMfma<M16, F16> MM;
   typedef typename MM::acc_t acc_t;
   constexpr int TS = MM::TS, KSN = MM::KSN, TMx = 32 * TM / TS, TNx = WTN / TS;   // MFMA tiles of a wave's 64 x WTN block
-  const float oscale = F16 ? a.xscale->inv * (1.f / (float)(1 << kWeightScaleLog2)) : 1.f;   // exact: powers of two
+  const float oscale = F16 ? inv_scale_of(a.xscale) * (1.f / (float)(1 << kWeightScaleLog2)) : 1.f;   // exact: powers of two
   const int wm = wid / WN, wn = wid % WN, lr = lane & (TS - 1), kq = lane / TS;
   // band index of this lane's pixel of N-tile j (centre tap)
   uint32_t hoff[TNx];
@@ -533,7 +533,7 @@ __global__ __launch_bounds__(768) void conv_fwd_bf16p3_kernel(ConvArgsP2 a) {
   typedef BandMfma<M16, F16> MM;
   typedef typename MM::acc_t acc_t;
   constexpr int TS = MM::TS, KSN = MM::KSN, TMx = 32 * TM / TS, TNx = WTN / TS;   // MFMA tiles of a wave's 32*TM x WTN block
-  const float oscale = F16 ? a.xscale->inv * (1.f / (float)(1 << kWeightScaleLog2)) : 1.f;   // exact: powers of two
+  const float oscale = F16 ? inv_scale_of(a.xscale) * (1.f / (float)(1 << kWeightScaleLog2)) : 1.f;   // exact: powers of two
   const int wm = wid / WN, wn = wid % WN, lr = lane & (TS - 1), kq = lane / TS;
   uint32_t hoff[TNx];
 #pragma unroll

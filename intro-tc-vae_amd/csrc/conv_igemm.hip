@@ -703,7 +703,7 @@ __global__ __launch_bounds__(512) void conv_fwd_bf16p_kernel(ConvArgsP a) {
   typedef BandMfma<M16, F16> MM;
   typedef typename MM::acc_t acc_t;
   constexpr int TS = MM::TS, TMx = WTM / TS, TNx = WTN / TS;
-  const float oscale = F16 ? a.xscale->inv * (1.f / (float)(1 << kWeightScaleLog2)) : 1.f;   // exact: powers of two
+  const float oscale = F16 ? inv_scale_of(a.xscale) * (1.f / (float)(1 << kWeightScaleLog2)) : 1.f;   // exact: powers of two
   const int wm = wid / WN, wn = wid % WN, lr = lane & (TS - 1), kq = lane / TS;
   acc_t acc[TMx][TNx];
 #pragma unroll
@@ -1551,7 +1551,7 @@ __global__ __launch_bounds__(512 + 64 * NLW) void conv_wgrad_bf16p_kernel(WgradA
     }
   }
   // slab[split][tap][co][ci]
-  const float oscale = F16 ? a.xscale->inv * a.dyscale->inv : 1.f;   // exact: powers of two
+  const float oscale = F16 ? inv_scale_of(a.xscale) * inv_scale_of(a.dyscale) : 1.f;   // exact: powers of two
 #pragma unroll
   for (int j = 0; j < TNw; ++j) {
     const int ci = ci0 + 32 * (wn * TNw + j) + l31;
@@ -1600,7 +1600,7 @@ __global__ __launch_bounds__(256) void conv_wgrad5_planes_kernel(const float* __
   float sscale = 1.f, oscale = 1.f;
   if constexpr (F16) {
     if (sm_amax) sscale = scale_for_bound(wave_absmax_of(sm_amax, kAbsmaxParts));
-    oscale = reinterpret_cast<const ScaleRec*>(tp + 2 * plane_stride)->inv / sscale;      // exact: powers of two
+    oscale = inv_scale_of(reinterpret_cast<const ScaleRec*>(tp + 2 * plane_stride)) / sscale;      // exact: powers of two
   }
   f32x4_t acc[5][4];
 #pragma unroll
@@ -2739,7 +2739,7 @@ int itcv_conv2d_wgrad5_bf16p(const float* small, const void* big_planes, float* 
   hipStream_t st = S(stream);
   const size_t plane_stride = (size_t)B * 8 * H * W;
   {
-    ProfScope prof(st, 2, 5, 64, 0, ns, 2.0 * B * H * W * 64.0 * Cs * 25);
+    ProfScope prof(st, 12, 5, Cs, stem ? 1 : 0, ns, 2.0 * B * H * W * 64.0 * Cs * 25);
     const dim3 grid(cdiv(njobs, 4)), blk(256);
     const u32x4* bp = static_cast<const u32x4*>(big_planes);
     float* slab = static_cast<float*>(ws);

@@ -171,7 +171,7 @@ __global__ __launch_bounds__(256) void conv_small_cout_planes_kernel(const u32x4
         af[dh][hf][1] = __builtin_bit_cast(bf16x8, pl[1]);
       }
   }
-  const float oscale = F16 ? reinterpret_cast<const ScaleRec*>(xp + 2 * plane_stride)->inv * (1.f / (float)(1 << kWeightScaleLog2)) : 1.f;
+  const float oscale = F16 ? inv_scale_of(reinterpret_cast<const ScaleRec*>(xp + 2 * plane_stride)) * (1.f / (float)(1 << kWeightScaleLog2)) : 1.f;
   const u32x4 zero = {0u, 0u, 0u, 0u};
   // B fragments of one input row: [half][plane], chunk (b, c8 = half*4 + kg, row, wc)
   auto load_row = [&](int hr, u32x4 (&dst)[2][2]) {
@@ -325,6 +325,12 @@ __global__ __launch_bounds__(256, 2) void conv_small_cin_mfma_kernel(const float
   for (int q = 0; q < R - 1; ++q) load_row(h0 - 2 + q, ring[q]);
   float* yb = y + (size_t)b * M * HW;            // uniform
   const int lane_off = 4 * kg * (int)HW + w0 + n;
+  // this lane's 32 bias values, loaded once (left in the store loop the compiler reloads one per stored element)
+  float bv[2][16];
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) bv[mt][r] = bias ? bias[mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg] : 0.f;
   for (int o0 = 0; o0 < nrows; o0 += R) {
 #pragma unroll
     for (int u = 0; u < R; ++u) {
@@ -353,7 +359,7 @@ __global__ __launch_bounds__(256, 2) void conv_small_cin_mfma_kernel(const float
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int mu = mt * 32 + (r & 3) + 8 * (r >> 2);   // + 4*kg inside lane_off
-          yr[(size_t)mu * HW + lane_off] = (F16 ? acc[mt][r] * oscale : acc[mt][r]) + (bias ? bias[mu + 4 * kg] : 0.f);
+          yr[(size_t)mu * HW + lane_off] = (F16 ? acc[mt][r] * oscale : acc[mt][r]) + bv[mt][r];
         }
     }
   }
@@ -424,7 +430,7 @@ int itcv_conv2d_small_cout_fwd_bf16p(const void* xplanes, const float* w, const 
   hipStream_t st = S(stream);
   const size_t plane_stride = (size_t)B * 8 * H * W;
   const u32x4* xp = static_cast<const u32x4*>(xplanes);
-  ProfScope prof(st, 4, KS, Co, 0, ns, 2.0 * B * H * W * (double)Co * C * KS * KS);
+  ProfScope prof(st, 10, KS, Co, 0, ns, 2.0 * B * H * W * (double)Co * C * KS * KS);
   const dim3 grid(cdiv(njobs, 4)), blk(256);
 #define ITCV_SCOUT_P(DG_, F_)                                                                                      \
   launch_timed((conv_small_cout_planes_kernel<DG_, F_>), grid, blk, 0, st, xp, w, bias, y, B, H, W, Co, strips, \
@@ -505,7 +511,7 @@ int itcv_conv2d_small_cin_fwd_bf16x3(const float* x, const float* w, const float
   row_blocks = cdiv(H, RB);
   const int njobs = B * row_blocks * strips;
   hipStream_t st = S(stream);
-  ProfScope prof(st, 5, KS, C, 0, ns, 2.0 * B * H * W * (double)Co * C * KS * KS);
+  ProfScope prof(st, 11, KS, C, 0, ns, 2.0 * B * H * W * (double)Co * C * KS * KS);
   // (Requesting each input row one output row ahead of its use -- AHEAD = 1 -- was measured slower, 37 -> 43 us at
   // 128 x 3 x 64 x 64: the kernel is bound by its 134 MB of stores, and the longer ring costs registers.)
 #define ITCV_SCIN_K(CI_, DG_, F_)                                                                                       \

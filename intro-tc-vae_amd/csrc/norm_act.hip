@@ -696,7 +696,25 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_planes(
   if constexpr (F16) {
     __shared__ float s_uv[8];
     float u = 0.f, v = 0.f;
-    for (int i = threadIdx.x; i < nmx; i += 256) u = fmaxf(u, mx[i]), v = fmaxf(v, mx[nmx + i]);
+    // nmx = groups * slices * C (C % 8 == 0): float4 loads, four of them in flight per array -- a plain scalar loop is
+    // one exposed L2 round trip per element
+    const float4* mu4 = reinterpret_cast<const float4*>(mx);
+    const float4* mv4 = reinterpret_cast<const float4*>(mx + nmx);
+    const int n4 = nmx >> 2;
+    for (int i = threadIdx.x; i < n4; i += 4 * 256) {
+      float4 tu[4], tv[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int idx = i + k * 256;
+        tu[k] = idx < n4 ? mu4[idx] : make_float4(0.f, 0.f, 0.f, 0.f);
+        tv[k] = idx < n4 ? mv4[idx] : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        u = fmaxf(fmaxf(u, fmaxf(tu[k].x, tu[k].y)), fmaxf(tu[k].z, tu[k].w));
+        v = fmaxf(fmaxf(v, fmaxf(tv[k].x, tv[k].y)), fmaxf(tv[k].z, tv[k].w));
+      }
+    }
     u = wave_max(u), v = wave_max(v);
     if ((threadIdx.x & 63) == 0) s_uv[threadIdx.x >> 6] = u, s_uv[4 + (threadIdx.x >> 6)] = v;
     __syncthreads();

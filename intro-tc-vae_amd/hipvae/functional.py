@@ -388,7 +388,8 @@ class LaunchProfile:
     the launch stream around the main kernel of every conv call (bench.py's roofline leg)."""
     KINDS = {0: "conv_fwd_kernel", 1: "conv_fwd_bf16s_kernel", 2: "conv_wgrad_kernel", 3: "conv_wgrad_bf16s_kernel",
              4: "conv_small_cout_kernel", 5: "conv_small_cin_kernel", 6: "conv_fwd_bf16p_kernel",
-             7: "conv_wgrad_bf16p_kernel", 8: "conv_fwd_bf16p2_kernel", 9: "conv_fwd_bf16p3_kernel"}
+             7: "conv_wgrad_bf16p_kernel", 8: "conv_fwd_bf16p2_kernel", 9: "conv_fwd_bf16p3_kernel",
+             10: "conv_small_cout_planes_kernel", 11: "conv_small_cin_mfma_kernel", 12: "conv_wgrad5_planes_kernel"}
 
     @classmethod
     def begin(cls):
@@ -411,6 +412,8 @@ class LaunchProfile:
                 label = f"{cls.KINDS[kind]}<LOG2W={ks},BM={bm},up2={up2},NS={ns}>"
             elif kind in (1, 3, 6):
                 label = f"{cls.KINDS[kind]}<KS={ks},BM={bm},up2={up2},NS={ns}>"
+            elif kind in (10, 11, 12):     # the 5x5 layers on the matrix cores: C = the narrow side's channels
+                label = f"{cls.KINDS[kind]}<KS={ks},C={bm},stem={up2},NS={ns}>"
             else:
                 label = f"{cls.KINDS[kind]}<KS={ks},C={bm}>"
             out.append((label, flop.value, ms.value * 1e-3))

@@ -240,14 +240,14 @@ def test_steps_conv_golden():
     run_golden_steps("steps_conv.npz", "conv", "mse", ("vae", "tc", "intro", "intro_tc"), 2)
 
 
-def test_use_amp_selects_split_bf16():
-    """use_amp=True (the reference config's default, inert there) maps to the bf16x3 conv arithmetic."""
+def test_use_amp_selects_split_fp16():
+    """use_amp=True (the reference config's default, inert there) maps to the f16x3 conv arithmetic (fp32-class)."""
     import models
     from solvers.intro_tc import IntroTCSovler
     m = models.SoftIntroVAE(arch="conv", **TINY).to(dev())
     mk = lambda amp: IntroTCSovler(_DS(10), m, 4, torch.optim.Adam(m.encoder.parameters()),  # noqa: E731
                                    torch.optim.Adam(m.decoder.parameters()), "mse", 1.0, 1.0, 1.0, 1e-8, dev(), amp, None)
-    assert mk(True).conv_math == "bf16x3" and mk(False).conv_math == "fp32"
+    assert mk(True).conv_math == "f16x3" and mk(False).conv_math == "fp32"
 
 
 def test_steps_res_golden():
@@ -325,7 +325,8 @@ def test_intro_tc_step_64x64_vs_oracle(math, c2_oracles):
 
 @pytest.mark.parametrize("math,size,zdim,channels,B", [
     ("fp32", 128, 256, (64, 128, 256, 512, 512), 4), ("bf16x3", 128, 256, (64, 128, 256, 512, 512), 4),
-    ("bf16x3", 256, 512, (64, 128, 256, 512, 512, 512), 2)])
+    ("f16x3", 128, 256, (64, 128, 256, 512, 512), 4), ("bf16x3", 256, 512, (64, 128, 256, 512, 512, 512), 2),
+    ("f16x3", 256, 512, (64, 128, 256, 512, 512, 512), 2)])
 def test_intro_tc_step_large_images_vs_oracle(math, size, zdim, channels, B):
     """BASELINE configs[2] / configs[4] shapes (128x128x3, z=256; 256x256x3, z=512) at a small batch: layers wider
     than the band / transposing-read kernels take (W > 64) run on the 128-pixel-tile and in-kernel-split forms --
@@ -386,34 +387,111 @@ def test_graph_replay_equals_eager():
     assert float((out["eager_w"] - out["graph_w"]).abs().max()) < 1e-6
 
 
-def test_full_size_c2_step_properties():
-    """BASELINE configs[1] at its full size (64x64x3, z=128, channels (64,128,256,512), batch 64, bf16x3 -- the bench
-    line's workload), where the CPU oracle takes minutes per step: size-independent properties instead.  (a) The same
-    three steps issued as 7 batched passes (persistent band kernels over 2048 tiles, no split-K) and as 13 passes one by
-    one (64-image launches: one-tile kernels, split-K on the 8x8 / 16x16 layers) agree -- two different sets of launch
-    shapes for every conv, BatchNorm and weight-gradient layer; (b) hipGraph replays reproduce the eager trajectory;
-    (c) every returned scalar is finite and the reconstruction loss falls over the steps."""
+# ---- solver x architecture x arithmetic at real channel widths (BASELINE configs[0]'s shape) -------------------------
+C1 = dict(cdim=3, zdim=10, channels=(64, 128, 256), image_size=32)
+_MATRIX_ORACLE = {}
+
+
+def _matrix_oracle(name, arch):
+    """One CPU-oracle step of solver ``name`` on architecture ``arch`` at the c1 shape (32x32x3, z=10, channels
+    (64,128,256), B=16), cached per (solver, arch): initial weights, inputs, returned dict and hook outputs."""
+    key = (name, arch)
+    if key not in _MATRIX_ORACLE:
+        import models
+        from oracle.network import Net
+        from oracle.steps import Trainer
+        torch.manual_seed(5)
+        sd = {k: v.clone() for k, v in models.SoftIntroVAE(arch=arch, **C1).state_dict().items()}
+        g = torch.Generator().manual_seed(17)
+        x = torch.rand(16, 3, 32, 32, generator=g)
+        draws = [torch.randn(16, 10, generator=g) for _ in range(6 if name.startswith("intro") else 1)]
+        tr = Trainer(name, Net(arch, state={k: v.clone() for k, v in sd.items()}, **C1), dataset_size=10000, beta_kl=0.5,
+                     beta_rec=0.75, beta_neg=512.0, gamma_r=1e-8, clip=100.0, lr=2e-4)
+        ref = tr.step(x, draws)
+        _MATRIX_ORACLE[key] = dict(sd=sd, x=x, draws=draws, ref=ref, kl=[t.clone() for t in tr.trace["kl"]],
+                                   rec=[t.clone() for t in tr.trace["rec"]])
+    return _MATRIX_ORACLE[key]
+
+
+@pytest.mark.parametrize("math", ["fp32", "f16x3", "bf16x6", "bf16x3"])
+@pytest.mark.parametrize("arch", ["conv", "res", "inception"])
+@pytest.mark.parametrize("name", ["vae", "tc", "intro", "intro_tc"])
+def test_solver_arch_math_matrix_vs_oracle(name, arch, math):
+    """Every solver (solvers/vae.py:89-136, tc.py:58-89, intro.py:56-196, intro_tc.py) on every architecture
+    (/root/reference/models.py:8-182) in every conv arithmetic, at channel widths that reach the planes / band / matrix-
+    core kernels, against the CPU oracle on identical weights, inputs and draws: the returned dict within 1e-4 (the clip
+    norm within 1e-3 in bf16x3), every compute_kl_loss / compute_rec_loss hook output of the phase that starts from the
+    identical weights within 3e-4 of its scale, the hook outputs behind the encoder's Adam update (phase D of the intro
+    solvers: weights whose gradient sits at rounding level move 2*lr apart) within 3e-3."""
     import models
+    import ops
+    o = _matrix_oracle(name, arch)
+    model = models.SoftIntroVAE(arch=arch, **C1)
+    model.load_state_dict(o["sd"])
+    model = model.to(dev()).train()
+    hp = [0.5, 0.75, 512.0, 1e-8, 100.0, 2e-4, 10000]
+    solver = make_solver(name, model, hp, math=math)
+    solver.batch_size = 16
+    kl_log, rec_log = [], []
+    kl0, rec0 = solver.compute_kl_loss, solver.compute_rec_loss
+    solver.compute_kl_loss = lambda *a, _f=kl0, **k: (kl_log.append(_f(*a, **k)), kl_log[-1])[1]
+    solver.compute_rec_loss = lambda *a, _f=rec0, **k: (rec_log.append(_f(*a, **k)), rec_log[-1])[1]
+    with ops.noise_queue([t.clone() for t in o["draws"]]):
+        d = solver.train_step(o["x"], 0)
+    for k in ("loss_enc", "loss_dec", "loss_kl", "loss_rec", "L2"):
+        tol = 1e-3 if (k == "L2" and math == "bf16x3") else 1e-4
+        assert abs(d[k] - o["ref"][k]) <= tol * abs(o["ref"][k]), (k, d[k], o["ref"][k])
+    assert len(kl_log) == len(o["kl"]) and len(rec_log) == len(o["rec"])
+    first = 3 if name.startswith("intro") else 99          # hook calls of the phase that starts from identical weights
+    for logs, refs in ((kl_log, o["kl"]), (rec_log, o["rec"])):
+        for i, (t, r) in enumerate(zip(logs, refs)):
+            tol = 3e-4 if i < first else 3e-3
+            err = float((t.detach().reshape(-1).cpu() - r).abs().max()) / float(r.abs().max())
+            assert err < tol, (i, err)
+
+
+FULL_SIZE = {  # BASELINE configs[1] / [2] / [4] at their full per-GPU batch
+    "c2": (C2, 64),
+    "c3": (dict(cdim=3, zdim=256, channels=(64, 128, 256, 512, 512), image_size=128), 128),
+    "c5": (dict(cdim=3, zdim=512, channels=(64, 128, 256, 512, 512, 512), image_size=256), 32),
+}
+
+
+@pytest.mark.parametrize("cfg,math", [("c2", "f16x3"), ("c2", "bf16x3"), ("c3", "f16x3"), ("c5", "f16x3")])
+def test_full_size_step_properties(cfg, math):
+    """BASELINE configs[1] (64x64x3, z=128, batch 64 -- the bench line's workload), configs[2] (128x128x3, z=256, batch
+    128) and configs[4] (256x256x3, z=512, 32 per GPU) at their FULL size, where the CPU oracle takes minutes per step:
+    size-independent properties instead.  (a) The same steps issued as 7 batched passes (persistent band kernels, no
+    split-K) and as 13 passes one by one (one-tile kernels, split-K on the small layers) agree -- two different sets of
+    launch shapes for every conv, BatchNorm and weight-gradient layer; (b) hipGraph replays reproduce the eager
+    trajectory; (c) every returned scalar is finite and the reconstruction loss falls over the steps."""
+    import models
+    net, B = FULL_SIZE[cfg]
+    S = net["image_size"]
     torch.manual_seed(11)
-    init = models.SoftIntroVAE(arch="conv", **C2).state_dict()
+    init = models.SoftIntroVAE(arch="conv", **net).state_dict()
     hp = [0.5, 0.75, 512.0, 1e-8, 100.0, 2e-4, 10000]
     g = torch.Generator().manual_seed(21)
-    xs = [torch.rand(64, 3, 64, 64, generator=g).to(dev()) for _ in range(6)]
+    nx = 6 if cfg == "c2" else 3
+    xs = [torch.rand(B, 3, S, S, generator=g).to(dev()) for _ in range(nx)]
 
     def run(batched, graph, nsteps):
-        model = models.SoftIntroVAE(arch="conv", **C2)
+        model = models.SoftIntroVAE(arch="conv", **net)
         model.load_state_dict(init)
         model = model.to(dev()).train()
-        solver = make_solver("intro_tc", model, hp, math="bf16x3")
-        solver.batch_size = 64
+        solver = make_solver("intro_tc", model, hp, math=math)
+        solver.batch_size = B
         solver.batch_passes = batched
         if graph:
             solver.enable_graph()
         torch.cuda.manual_seed(77)                       # the step draws its noise from the device generator
-        res = [solver.train_step(xs[i], i) for i in range(nsteps)]
+        res = [solver.train_step(xs[i % nx], i) for i in range(nsteps)]
         if graph:
             assert solver._graph is not None
-        return res, torch.cat([p.detach().reshape(-1) for p in model.parameters()]).cpu()
+        w = torch.cat([p.detach().reshape(-1) for p in model.parameters()]).cpu()
+        del solver, model
+        torch.cuda.empty_cache()
+        return res, w
 
     (rb, wb), (ru, wu) = run(True, False, 3), run(False, False, 3)
     # step 0 (identical weights): every scalar to 1e-5 (measured 3e-7 / 1e-6, the clip norm L2 1.5e-5 -> 1e-4).  From
@@ -427,7 +505,8 @@ def test_full_size_c2_step_properties():
     assert float((wb - wu).abs().max()) <= 2.05 * 3 * 2e-4
     assert float((wb - wu).abs().mean()) < 1.5e-4       # a quarter of the largest possible total update
     assert rb[2]["loss_rec"] < rb[0]["loss_rec"]
-    (rg, wg), (re_, we) = run(True, True, 6), run(True, False, 6)
+    ng = 6 if cfg == "c2" else 5
+    (rg, wg), (re_, we) = run(True, True, ng), run(True, False, ng)
     for a, b in zip(rg, re_):
         for k in a:
             assert abs(a[k] - b[k]) <= 1e-5 * abs(b[k]) + 1e-9, (k, a[k], b[k])

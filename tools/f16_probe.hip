@@ -64,23 +64,34 @@ int main() {
     unsigned lo = ((rand() & 0x807F) | ((123 + rand() % 8) << 7)), hi = ((rand() & 0x807F) | ((123 + rand() % 8) << 7));
     v = lo | (hi << 16);
   }
-  unsigned *ds, *dsb;
+  // fp16 operands with half of the elements SUBNORMAL (exponent field 0), as the lo plane of O(1) activations has
+  std::vector<unsigned> srcd(1 << 20);
+  for (auto& v : srcd) {
+    unsigned lo = (rand() & 1) ? (rand() & 0x83FF) : ((rand() & 0x83FF) | ((11 + rand() % 8) << 10));
+    unsigned hi = (rand() & 1) ? (rand() & 0x83FF) : ((rand() & 0x83FF) | ((11 + rand() % 8) << 10));
+    v = lo | (hi << 16);
+  }
+  unsigned *ds, *dsb, *dsd;
   hipMalloc(&ds, 4 << 20);
   hipMalloc(&dsb, 4 << 20);
+  hipMalloc(&dsd, 4 << 20);
+  hipMemcpy(dsd, srcd.data(), 4 << 20, hipMemcpyHostToDevice);
   hipMemcpy(ds, src.data(), 4 << 20, hipMemcpyHostToDevice);
   hipMemcpy(dsb, srcb.data(), 4 << 20, hipMemcpyHostToDevice);
   hipEvent_t e0, e1;
   hipEventCreate(&e0), hipEventCreate(&e1);
   const int iters = 4000, blocks = 1024;
   for (int rep = 0; rep < 3; ++rep)
-    for (int f = 0; f < 2; ++f) {
+    for (int f = 0; f < 3; ++f) {
       for (int w = 0; w < 20; ++w) {
-        if (f) rate_probe<true><<<blocks, 256>>>(ds, d, iters);
+        if (f == 2) rate_probe<true><<<blocks, 256>>>(dsd, d, iters);
+        else if (f) rate_probe<true><<<blocks, 256>>>(ds, d, iters);
         else rate_probe<false><<<blocks, 256>>>(dsb, d, iters);
       }
       hipEventRecord(e0);
       for (int w = 0; w < 20; ++w) {
-        if (f) rate_probe<true><<<blocks, 256>>>(ds, d, iters);
+        if (f == 2) rate_probe<true><<<blocks, 256>>>(dsd, d, iters);
+        else if (f) rate_probe<true><<<blocks, 256>>>(ds, d, iters);
         else rate_probe<false><<<blocks, 256>>>(dsb, d, iters);
       }
       hipEventRecord(e1);
@@ -88,7 +99,7 @@ int main() {
       float ms;
       hipEventElapsedTime(&ms, e0, e1);
       double flop = 20.0 * blocks * 4 * iters * 8 * 2.0 * 16 * 16 * 32;
-      printf("%s 16x16x32 random data: %.1f TFLOP/s\n", f ? "f16 " : "bf16", flop / (ms * 1e-3) / 1e12);
+      printf("%s 16x16x32 random data: %.1f TFLOP/s\n", f == 2 ? "f16 (half subnormal)" : (f ? "f16 " : "bf16"), flop / (ms * 1e-3) / 1e12);
     }
   return 0;
 }

@@ -1,4 +1,4 @@
-"""Training trajectories of the three conv arithmetic modes on the benchmark configuration (c2, B=64): the same
+"""Training trajectories of the four conv arithmetic modes on the benchmark configuration (c2, B=64): the same
 weights, batches and device noise stream, STEPS intro-tc steps each; prints loss_rec / loss_kl / loss_enc / loss_dec
 averaged over windows of 50 steps and the relative difference of every mode to exact fp32.  Chaotic divergence of
 individual steps is expected (Adam's sign-like early updates amplify 1e-7 differences); the
@@ -54,7 +54,7 @@ def run(mode, perturb=False):
     return out
 
 
-res = {m: run(m) for m in ("fp32", "bf16x6", "bf16x3")}
+res = {m: run(m) for m in ("fp32", "f16x3", "bf16x6", "bf16x3")}
 res["fp32_weights_x(1+1e-7)"] = run("fp32", perturb=True)
 rel = {m: [{k: abs(w[k] - r[k]) / (abs(r[k]) + 1e-12) for k in w} for w, r in zip(res[m], res["fp32"])]
        for m in res if m != "fp32"}
