@@ -321,6 +321,23 @@ int itcv_tc_bwd(const float* g, const float* z, const float* mu_all, const float
                 const float* logqz, const float* lse, const float* sjoint, float* dz, float* dmu_all,
                 float* dlogvar, int Bl, int Bt, int row_offset, int D, int64_t dataset_size, int flags, void* ws,
                 size_t ws_bytes, void* stream);
+/* The whole KL hook of the TC solvers, solvers/tc.py:69-89: (beta - 1) * total_correlation + kl_divergence with the
+ * hook's reduction, fused into the estimator's launches: out[Bl] (reduction 0 none) or out[1] (1 sum, 2 mean) of
+ * coef_tc * (logqz_j - prodm_j) + coef_kl * kl_j, kl_j = ops.py:161-163 on this rank's rows (mu_all + row_offset*D, logvar).
+ * rows[Bl]: scratch of the reduced forms.  prodm / logqz / lse / sjoint as itcv_tc_fwd (kept for _bwd).
+ * _bwd: g is [Bl] (none) or [1]; dz, dlogvar (rows) and dmu_all (columns; the KL's d/dmu added at this rank's rows). */
+int itcv_tc_kl_fwd(const float* z, const float* mu_all, const float* logvar, float* out, float* rows, float* prodm,
+                   float* logqz, float* lse, float* sjoint, int Bl, int Bt, int row_offset, int D, int64_t dataset_size,
+                   float coef_tc, float coef_kl, int reduction, void* ws, size_t ws_bytes, void* stream);
+int itcv_tc_kl_bwd(const float* g, const float* z, const float* mu_all, const float* logvar, const float* logqz,
+                   const float* lse, const float* sjoint, float* dz, float* dmu_all, float* dlogvar, int Bl, int Bt,
+                   int row_offset, int D, int64_t dataset_size, float coef_tc, float coef_kl, int reduction, void* ws,
+                   size_t ws_bytes, void* stream);
+/* ops.kl_divergence with its reduction and the hook's `beta *` (ops.py:136-163, solvers/vae.py:63-77) in one launch:
+ * reduction 0: out[B] = scale * kl_j; 1 / 2: out[1] = scale * sum_j kl_j [/ B]; _bwd for g of that shape. */
+int itcv_kl_loss_fwd(const float* logvar, const float* mu, float* out, int B, int D, int reduction, float scale, void* stream);
+int itcv_kl_loss_bwd(const float* g, const float* logvar, const float* mu, float* dlogvar, float* dmu, int B, int D,
+                     int reduction, float scale, void* stream);
 /* solvers/tc.py:104-121: per-sample log q(z|x) (ops.py:24-29 density, own mu/logvar) and log p(z) */
 int itcv_diag_logdensity_rows(const float* z, const float* mu, const float* logvar, float* logq_cx,
                               float* logpz, int B, int D, void* stream);
@@ -356,6 +373,22 @@ size_t itcv_recon_workspace(int B, size_t P);
 /* drecon[b][p] = g[b] * d err / d recon */
 int itcv_recon_rows_bwd(const float* x, const float* recon, const float* g, float* drecon, int B, size_t P,
                         int loss_type, void* stream);
+
+/* The whole of ops.reconstruction_loss plus the hook's `beta *` (ops.py:219-236, solvers/vae.py:79-87) in two launches:
+ * reduction 0 none: out[B] = scale * rows; 1 sum / 2 mean: out[1] = scale * sum_b rows [/ B].  _bwd: drecon for the
+ * gradient g of out ([B] for none, [1] else).  Workspace: itcv_recon_workspace. */
+int itcv_recon_loss_fwd(const float* x, const float* recon, float* out, int B, size_t P, int loss_type, int reduction,
+                        float scale, void* ws, size_t ws_bytes, void* stream);
+int itcv_recon_loss_bwd(const float* x, const float* recon, const float* g, float* drecon, int B, size_t P,
+                        int loss_type, int reduction, float scale, void* stream);
+/* solvers/intro.py:102-103: out[0] = mean_j exp(c * (a[j] + b[j])) (c = -2 * scale); w[B] is kept for _bwd, which
+ * writes da[j] = db[j] = g[0] * d out / d a[j] (db may be NULL). */
+int itcv_exp_elbo_fwd(const float* a, const float* b, float* out, float* w, int B, float c, void* stream);
+int itcv_exp_elbo_bwd(const float* g, const float* w, float* da, float* db, int B, void* stream);
+/* out[0] = sum_k weights[k] * terms[k][0], n <= 8 device scalars (solvers/intro.py:105-108,149-151, solvers/vae.py:106:
+ * the scalar arithmetic of a loss in one launch); _bwd: grads[k] = g[0] * weights[k].  `terms` / `weights` are HOST arrays. */
+int itcv_lincomb_fwd(const float* const* terms, const float* weights, int n, float* out, void* stream);
+int itcv_lincomb_bwd(const float* g, const float* weights, int n, float* grads, void* stream);
 
 /* ---- optimiser (train.py:141-144, solvers/intro.py:109-116,153-160) --------------------- */
 /* out[0] = sum x^2 (fp64, deterministic) */

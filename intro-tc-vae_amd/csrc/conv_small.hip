@@ -191,6 +191,7 @@ __global__ __launch_bounds__(256) void conv_small_cout_planes_kernel(const u32x4
   load_row(h0 - 2, cur);
   load_row(h0 - 1, nxt);
   float* zt = zs[wv];
+  const float bias_l = (bias && lane < 36 && lane / 12 < CO) ? bias[lane / 12] : 0.f;   // the output channel of this lane's fold
   for (int i0 = 0; i0 < nrows + 4; i0 += 5) {
 #pragma unroll
     for (int r = 0; r < 5; ++r) {
@@ -221,10 +222,10 @@ __global__ __launch_bounds__(256) void conv_small_cout_planes_kernel(const u32x4
         if (lane < 36) {
           const int co = lane / 12, nn = lane - co * 12, wo = s * 12 + nn;
           if (co < CO && wo < W) {
-            float v = (bias && !F16) ? bias[co] : 0.f;
+            float v = F16 ? 0.f : bias_l;
 #pragma unroll
             for (int dw = 0; dw < 5; ++dw) v += zt[(co * 5 + dw) * 17 + nn + dw];
-            if (F16) v = v * oscale + (bias ? bias[co] : 0.f);
+            if (F16) v = v * oscale + bias_l;
             y[(((size_t)b * CO + co) * H + (h0 + o)) * W + wo] = v;
           }
         }

@@ -154,11 +154,21 @@ __global__ __launch_bounds__(256) void tc_fwd_part_kernel(const float* __restric
 }
 
 // stage 2: block per row j -- lse[j][l], prodm[j], logqz[j]
+// Fused hook tail (solvers/tc.py:80-89): with `rows` set the block also evaluates the analytic KL of its sample,
+// kl_j = -0.5 sum_l (1 + lv - e^lv - mu^2) (ops.py:161-163; mu_loc / lv_loc: this rank's rows), and writes
+// rows[j] = coef_tc * (logqz_j - prodm_j) + coef_kl * kl_j  ((beta - 1) * TC + KL per sample, times the hook's scale).
+struct TcKlOut {
+  const float* mu_loc;
+  const float* lv_loc;
+  float* rows;
+  float coef_tc, coef_kl;
+};
+
 template <bool MWS>
 __global__ __launch_bounds__(256) void tc_fwd_finish_kernel(const float* __restrict__ pmax, const float* __restrict__ psum,
                                                             const float* __restrict__ sjoint, float* __restrict__ prodm,
                                                             float* __restrict__ logqz, float* __restrict__ lse, int Bt, int D,
-                                                            int nch, TcConst c) {
+                                                            int nch, TcConst c, TcKlOut kk) {
   __shared__ float red[4];
   const int j = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   float prod_acc = 0.f;
@@ -185,10 +195,31 @@ __global__ __launch_bounds__(256) void tc_fwd_finish_kernel(const float* __restr
   for (int i = tid; i < Bt; i += 256) se += expf(sjoint[(size_t)j * Bt + i] - mx);
   se = block_sum(se, red);
   const float pm = block_sum(prod_acc, red);
-  if (tid == 0) {
-    logqz[j] = mx + logf(se) - (MWS ? c.log_bn : 0.f);
-    prodm[j] = pm;
+  float klj = 0.f;
+  if (kk.rows) {
+    float a = 0.f;
+    for (int l = tid; l < D; l += 256) {
+      const float v = kk.lv_loc[(size_t)j * D + l], m = kk.mu_loc[(size_t)j * D + l];
+      a += 1.f + v - expf(v) - m * m;
+    }
+    klj = -0.5f * block_sum(a, red);
   }
+  if (tid == 0) {
+    const float lq = mx + logf(se) - (MWS ? c.log_bn : 0.f);
+    logqz[j] = lq;
+    prodm[j] = pm;
+    if (kk.rows) kk.rows[j] = kk.coef_tc * (lq - pm) + kk.coef_kl * klj;
+  }
+}
+
+// out[0] = scale * sum_j rows[j] (/ B for mean): the reduction of a per-sample loss vector in one launch
+__global__ __launch_bounds__(256) void rows_reduce_kernel(const float* __restrict__ rows, float* __restrict__ out, int B,
+                                                         int mean, float scale) {
+  __shared__ double red[4];
+  double a = 0.0;
+  for (int j = threadIdx.x; j < B; j += 256) a += (double)rows[j];
+  a = block_sum(a, red);
+  if (threadIdx.x == 0) out[0] = scale * (float)(mean ? a / (double)B : a);
 }
 
 // ---- backward of sum_j g[j]*(logqz[j]-prodm[j]), live path (VROW, EPS, MSS) ------------------
@@ -196,8 +227,17 @@ __global__ __launch_bounds__(256) void tc_fwd_finish_kernel(const float* __restr
 //   dz[j,l] = -sum_i G d/vhat_j,  dlogvar[j,l] = -var_j * sum_i G * 0.5*(1/vhat_j - (d/vhat_j)^2)   (straight-through clamp)
 //   dmu[i,l] = sum_j G d/vhat_j
 // Row kernel: block (j, 64-wide slice of l); the four waves split the columns i; also writes wq for the column kernel.
+// Upstream gradient of the fused op: per row g[j] (bcast == 0) or one scalar g[0] (a reduced output); row j's TC term
+// receives coef_tc * that, its KL term coef_kl * that (the plain estimator: coef_tc = 1, coef_kl = 0).
+struct TcGrad {
+  const float* g;
+  int bcast;
+  float coef_tc, coef_kl;
+};
+__device__ __forceinline__ float tc_g(const TcGrad& t, int j) { return t.bcast ? t.g[0] : t.g[j]; }
+
 __global__ __launch_bounds__(256) void tc_bwd_rows_kernel(
-    const float* __restrict__ g, const float* __restrict__ z, const float* __restrict__ mu_all,
+    TcGrad tg, const float* __restrict__ z, const float* __restrict__ mu_all,
     const float* __restrict__ logvar, const float* __restrict__ logqz, const float* __restrict__ lse,
     const float* __restrict__ sjoint, float* __restrict__ wq, float* __restrict__ dz, float* __restrict__ dlogvar, int Bt,
     int row_offset, int D, TcConst c) {
@@ -205,7 +245,7 @@ __global__ __launch_bounds__(256) void tc_bwd_rows_kernel(
   const int j = blockIdx.x, jg = row_offset + j, l = blockIdx.y * 64 + (threadIdx.x & 63);
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const bool act = l < D;
-  const float gj = g[j], lq = logqz[j];
+  const float gr = tc_g(tg, j), gj = tg.coef_tc * gr, gk = tg.coef_kl * gr, lq = logqz[j];
   const float zj = act ? z[(size_t)j * D + l] : 0.f, lvj = act ? logvar[(size_t)j * D + l] : 0.f;
   const float var = expf(lvj), vh = fmaxf(var, kVarEps), lvh = logf(vh), ivh = 1.f / vh;
   const float ls = act ? lse[(size_t)j * D + l] : 0.f;
@@ -230,13 +270,15 @@ __global__ __launch_bounds__(256) void tc_bwd_rows_kernel(
   __syncthreads();
   if (wid == 0 && act) {
     dz[(size_t)j * D + l] = (raz[0][lane] + raz[1][lane]) + (raz[2][lane] + raz[3][lane]);
-    dlogvar[(size_t)j * D + l] = ((rav[0][lane] + rav[1][lane]) + (rav[2][lane] + rav[3][lane])) * var;
+    // + the analytic KL's own d/dlogvar = -0.5 (1 - e^lv) (ops.py:161-163), weighted by gk (0 for the plain estimator)
+    const float dl = ((rav[0][lane] + rav[1][lane]) + (rav[2][lane] + rav[3][lane])) * var;
+    dlogvar[(size_t)j * D + l] = gk != 0.f ? dl + gk * (-0.5f) * (1.f - var) : dl;
   }
 }
 
 // Column kernel: block (i, 64-wide slice of l); the four waves split the rows j.
 __global__ __launch_bounds__(256) void tc_bwd_cols_kernel(
-    const float* __restrict__ g, const float* __restrict__ z, const float* __restrict__ mu_all,
+    TcGrad tg, const float* __restrict__ z, const float* __restrict__ mu_all,
     const float* __restrict__ logvar, const float* __restrict__ lse, const float* __restrict__ wq,
     float* __restrict__ dmu_all, int Bl, int Bt, int row_offset, int D, TcConst c) {
   __shared__ float racc[4][64];
@@ -247,7 +289,7 @@ __global__ __launch_bounds__(256) void tc_bwd_cols_kernel(
   float acc = 0.f;
 #pragma unroll 2
   for (int j = wid; j < Bl; j += 4) {
-    const float gj = g[j], q = wq[(size_t)j * Bt + i], liw = log_iw(c, row_offset + j, i);
+    const float gj = tg.coef_tc * tc_g(tg, j), q = wq[(size_t)j * Bt + i], liw = log_iw(c, row_offset + j, i);
     if (act) {
       const float vh = fmaxf(expf(logvar[(size_t)j * D + l]), kVarEps), ivh = 1.f / vh;
       const float d = z[(size_t)j * D + l] - mi;
@@ -257,7 +299,12 @@ __global__ __launch_bounds__(256) void tc_bwd_cols_kernel(
   }
   racc[wid][lane] = acc;
   __syncthreads();
-  if (wid == 0 && act) dmu_all[(size_t)i * D + l] = (racc[0][lane] + racc[1][lane]) + (racc[2][lane] + racc[3][lane]);
+  if (wid == 0 && act) {
+    float v = (racc[0][lane] + racc[1][lane]) + (racc[2][lane] + racc[3][lane]);
+    // the analytic KL's d/dmu = mu for this rank's own rows (column i is local row i - row_offset)
+    if (tg.coef_kl != 0.f && i >= row_offset && i < row_offset + Bl) v += tg.coef_kl * tc_g(tg, i - row_offset) * mi;
+    dmu_all[(size_t)i * D + l] = v;
+  }
 }
 
 // solvers/tc.py:104-109: log q(z_j|x_j) and log p(z_j) with the ops.py:24-29 density
@@ -431,6 +478,46 @@ __global__ void on_off_diag_kernel(const float* __restrict__ x, float* __restric
   }
 }
 
+// ops.kl_divergence + the hook's `beta *` (ops.py:136-163, solvers/vae.py:63-77) in one launch: the waves of ONE block
+// walk the rows; reduction 0: out[j] = scale * kl_j, 1 / 2: out[0] = scale * sum_j kl_j [/ B]
+__global__ __launch_bounds__(1024) void kl_loss_fwd_kernel(const float* __restrict__ lv, const float* __restrict__ mu,
+                                                          float* __restrict__ out, int B, int D, int reduction, float scale) {
+  __shared__ double part[16];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  double acc = 0.0;
+  for (int j = w; j < B; j += 16) {
+    float a = 0.f;
+    for (int l = lane; l < D; l += 64) {
+      const float v = lv[(size_t)j * D + l], m = mu[(size_t)j * D + l];
+      a += 1.f + v - expf(v) - m * m;
+    }
+    const float kl = -0.5f * wave_sum(a);
+    if (reduction == 0) {
+      if (lane == 0) out[j] = scale * kl;
+    } else {
+      acc += (double)kl;
+    }
+  }
+  if (reduction == 0) return;
+  if (lane == 0) part[w] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = 0.0;
+    for (int k = 0; k < 16; ++k) t += part[k];
+    out[0] = scale * (float)(reduction == 2 ? t / (double)B : t);
+  }
+}
+__global__ void kl_loss_bwd_kernel(const float* __restrict__ g, const float* __restrict__ lv, const float* __restrict__ mu,
+                                   float* __restrict__ dlv, float* __restrict__ dmu, int D, size_t n, int reduction,
+                                   float coef) {
+  const float g0 = reduction ? g[0] * coef : 0.f;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const float gj = reduction ? g0 : g[i / D] * coef;
+    dlv[i] = gj * (-0.5f) * (1.f - expf(lv[i]));
+    dmu[i] = gj * mu[i];
+  }
+}
+
 static int make_const(const char* name, int Bt, int64_t N, TcConst* c) {
   if (Bt < 2) return fail("%s: batch size must be >= 2 (M = B-1 divides the weights; ops.py:43-45)", name);
   if (N <= 0) return fail("%s: dataset_size must be positive", name);
@@ -489,9 +576,10 @@ size_t itcv_tc_fwd_workspace(int Bl, int Bt, int D) {
   return Bl > 0 && Bt > 0 && D > 0 ? (size_t)2 * Bl * tc_chunks(Bt) * D * sizeof(float) : 0;
 }
 
-int itcv_tc_fwd(const float* z, const float* mu_all, const float* logvar, float* prodm, float* logqz, float* lse,
-                float* sjoint, int Bl, int Bt, int row_offset, int D, int64_t dataset_size, int flags, void* ws,
-                size_t ws_bytes, void* stream) {
+}  // extern "C"
+static int tc_fwd_impl(const float* z, const float* mu_all, const float* logvar, float* prodm, float* logqz, float* lse,
+                       float* sjoint, int Bl, int Bt, int row_offset, int D, int64_t dataset_size, int flags, void* ws,
+                       size_t ws_bytes, const TcKlOut& kk, void* stream) {
   ITCV_REQUIRE(z && mu_all && logvar && prodm && logqz && lse && sjoint && Bl > 0 && D > 0, "itcv_tc_fwd");
   ITCV_REQUIRE(row_offset >= 0 && row_offset + Bl <= Bt, "itcv_tc_fwd(rows must lie inside the global batch)");
   if (D > 64 * kTcDLMax) return fail("%s: latent size %lld > 512 is not supported", "itcv_tc_fwd", D);
@@ -533,19 +621,43 @@ int itcv_tc_fwd(const float* z, const float* mu_all, const float* logvar, float*
 #undef ITCV_TC_PART
   ITCV_CHECK_LAUNCH("itcv_tc_fwd(partials)");
   if (mws)
-    hipLaunchKernelGGL(tc_fwd_finish_kernel<true>, dim3(Bl), block, 0, st, pmax, psum, sjoint, prodm, logqz, lse, Bt, D, nch, c);
+    hipLaunchKernelGGL(tc_fwd_finish_kernel<true>, dim3(Bl), block, 0, st, pmax, psum, sjoint, prodm, logqz, lse, Bt, D, nch, c, kk);
   else
-    hipLaunchKernelGGL(tc_fwd_finish_kernel<false>, dim3(Bl), block, 0, st, pmax, psum, sjoint, prodm, logqz, lse, Bt, D, nch, c);
+    hipLaunchKernelGGL(tc_fwd_finish_kernel<false>, dim3(Bl), block, 0, st, pmax, psum, sjoint, prodm, logqz, lse, Bt, D, nch, c, kk);
   ITCV_CHECK_LAUNCH("itcv_tc_fwd(finish)");
+  return 0;
+}
+extern "C" {
+int itcv_tc_fwd(const float* z, const float* mu_all, const float* logvar, float* prodm, float* logqz, float* lse,
+                float* sjoint, int Bl, int Bt, int row_offset, int D, int64_t dataset_size, int flags, void* ws,
+                size_t ws_bytes, void* stream) {
+  return tc_fwd_impl(z, mu_all, logvar, prodm, logqz, lse, sjoint, Bl, Bt, row_offset, D, dataset_size, flags, ws, ws_bytes,
+                     TcKlOut{nullptr, nullptr, nullptr, 0.f, 0.f}, stream);
+}
+
+int itcv_tc_kl_fwd(const float* z, const float* mu_all, const float* logvar, float* out, float* rows, float* prodm,
+                   float* logqz, float* lse, float* sjoint, int Bl, int Bt, int row_offset, int D, int64_t dataset_size,
+                   float coef_tc, float coef_kl, int reduction, void* ws, size_t ws_bytes, void* stream) {
+  ITCV_REQUIRE(out && (reduction == 0 || rows) && reduction >= 0 && reduction <= 2, "itcv_tc_kl_fwd");
+  ITCV_REQUIRE(mu_all && row_offset >= 0 && row_offset + Bl <= Bt, "itcv_tc_kl_fwd(rows must lie inside the global batch)");
+  const TcKlOut kk{mu_all + (size_t)row_offset * D, logvar, reduction == 0 ? out : rows, coef_tc, coef_kl};
+  if (int e = tc_fwd_impl(z, mu_all, logvar, prodm, logqz, lse, sjoint, Bl, Bt, row_offset, D, dataset_size, ITCV_TC_LIVE, ws,
+                          ws_bytes, kk, stream))
+    return e;
+  if (reduction) {
+    hipLaunchKernelGGL(rows_reduce_kernel, dim3(1), dim3(256), 0, S(stream), rows, out, Bl, reduction == 2 ? 1 : 0, 1.f);
+    ITCV_CHECK_LAUNCH("itcv_tc_kl_fwd(reduce)");
+  }
   return 0;
 }
 
 size_t itcv_tc_bwd_workspace(int Bl, int Bt) { return Bl > 0 && Bt > 0 ? (size_t)Bl * Bt * sizeof(float) : 0; }
 
-int itcv_tc_bwd(const float* g, const float* z, const float* mu_all, const float* logvar, const float* logqz,
-                const float* lse, const float* sjoint, float* dz, float* dmu_all, float* dlogvar, int Bl, int Bt,
-                int row_offset, int D, int64_t dataset_size, int flags, void* ws, size_t ws_bytes, void* stream) {
-  ITCV_REQUIRE(g && z && mu_all && logvar && logqz && lse && sjoint && dz && dmu_all && dlogvar && Bl > 0 && D > 0,
+}  // extern "C"
+static int tc_bwd_impl(const TcGrad& tg, const float* z, const float* mu_all, const float* logvar, const float* logqz,
+                       const float* lse, const float* sjoint, float* dz, float* dmu_all, float* dlogvar, int Bl, int Bt,
+                       int row_offset, int D, int64_t dataset_size, int flags, void* ws, size_t ws_bytes, void* stream) {
+  ITCV_REQUIRE(tg.g && z && mu_all && logvar && logqz && lse && sjoint && dz && dmu_all && dlogvar && Bl > 0 && D > 0,
                "itcv_tc_bwd");
   ITCV_REQUIRE(row_offset >= 0 && row_offset + Bl <= Bt, "itcv_tc_bwd(rows must lie inside the global batch)");
   if (flags != ITCV_TC_LIVE)
@@ -556,12 +668,44 @@ int itcv_tc_bwd(const float* g, const float* z, const float* mu_all, const float
   float* wq = static_cast<float*>(ws);
   hipStream_t st = S(stream);
   const int lch = cdiv(D, 64);
-  hipLaunchKernelGGL(tc_bwd_rows_kernel, dim3(Bl, lch), dim3(256), 0, st, g, z, mu_all, logvar, logqz, lse, sjoint, wq, dz,
+  hipLaunchKernelGGL(tc_bwd_rows_kernel, dim3(Bl, lch), dim3(256), 0, st, tg, z, mu_all, logvar, logqz, lse, sjoint, wq, dz,
                      dlogvar, Bt, row_offset, D, c);
   ITCV_CHECK_LAUNCH("itcv_tc_bwd(rows)");
-  hipLaunchKernelGGL(tc_bwd_cols_kernel, dim3(Bt, lch), dim3(256), 0, st, g, z, mu_all, logvar, lse, wq, dmu_all, Bl, Bt,
+  hipLaunchKernelGGL(tc_bwd_cols_kernel, dim3(Bt, lch), dim3(256), 0, st, tg, z, mu_all, logvar, lse, wq, dmu_all, Bl, Bt,
                      row_offset, D, c);
   ITCV_CHECK_LAUNCH("itcv_tc_bwd(cols)");
+  return 0;
+}
+extern "C" {
+int itcv_tc_bwd(const float* g, const float* z, const float* mu_all, const float* logvar, const float* logqz,
+                const float* lse, const float* sjoint, float* dz, float* dmu_all, float* dlogvar, int Bl, int Bt,
+                int row_offset, int D, int64_t dataset_size, int flags, void* ws, size_t ws_bytes, void* stream) {
+  return tc_bwd_impl(TcGrad{g, 0, 1.f, 0.f}, z, mu_all, logvar, logqz, lse, sjoint, dz, dmu_all, dlogvar, Bl, Bt, row_offset,
+                     D, dataset_size, flags, ws, ws_bytes, stream);
+}
+int itcv_tc_kl_bwd(const float* g, const float* z, const float* mu_all, const float* logvar, const float* logqz,
+                   const float* lse, const float* sjoint, float* dz, float* dmu_all, float* dlogvar, int Bl, int Bt,
+                   int row_offset, int D, int64_t dataset_size, float coef_tc, float coef_kl, int reduction, void* ws,
+                   size_t ws_bytes, void* stream) {
+  ITCV_REQUIRE(reduction >= 0 && reduction <= 2, "itcv_tc_kl_bwd");
+  const float r = reduction == 2 ? 1.f / (float)Bl : 1.f;
+  return tc_bwd_impl(TcGrad{g, reduction ? 1 : 0, coef_tc * r, coef_kl * r}, z, mu_all, logvar, logqz, lse, sjoint, dz, dmu_all,
+                     dlogvar, Bl, Bt, row_offset, D, dataset_size, ITCV_TC_LIVE, ws, ws_bytes, stream);
+}
+
+int itcv_kl_loss_fwd(const float* logvar, const float* mu, float* out, int B, int D, int reduction, float scale, void* stream) {
+  ITCV_REQUIRE(logvar && mu && out && B > 0 && D > 0 && reduction >= 0 && reduction <= 2, "itcv_kl_loss_fwd");
+  hipLaunchKernelGGL(kl_loss_fwd_kernel, dim3(1), dim3(1024), 0, S(stream), logvar, mu, out, B, D, reduction, scale);
+  ITCV_CHECK_LAUNCH("itcv_kl_loss_fwd");
+  return 0;
+}
+int itcv_kl_loss_bwd(const float* g, const float* logvar, const float* mu, float* dlogvar, float* dmu, int B, int D,
+                     int reduction, float scale, void* stream) {
+  ITCV_REQUIRE(g && logvar && mu && dlogvar && dmu && B > 0 && D > 0 && reduction >= 0 && reduction <= 2, "itcv_kl_loss_bwd");
+  const size_t n = (size_t)B * D;
+  hipLaunchKernelGGL(kl_loss_bwd_kernel, dim3(ew_grid(n)), dim3(256), 0, S(stream), g, logvar, mu, dlogvar, dmu, D, n, reduction,
+                     reduction == 2 ? scale / (float)B : scale);
+  ITCV_CHECK_LAUNCH("itcv_kl_loss_bwd");
   return 0;
 }
 

@@ -61,6 +61,73 @@ __global__ void recon_bwd_kernel(const float* __restrict__ x, const float* __res
     drecon[i] = g[i / P] * rec_derr<LT>(recon[i], x[i]);
 }
 
+// Fused tail of ops.reconstruction_loss (ops.py:230-236) and of the solver hook's `beta *` (solvers/vae.py:79-87): one
+// block folds the slice sums into rows[b] (kept for a caller that wants them) and writes
+//   reduction 0 (none): out[b] = scale * rows[b];  1 (sum): out[0] = scale * sum_b rows[b];  2 (mean): out[0] = scale * mean_b rows[b]
+__global__ __launch_bounds__(256) void recon_finish_kernel(const double* __restrict__ part, float* __restrict__ out, int B,
+                                                          int splits, int reduction, float scale) {
+  __shared__ double scratch[4];
+  double acc = 0.0;
+  for (int b = threadIdx.x; b < B; b += 256) {
+    const float row = (float)fold_strided(0.0, part + (size_t)b * splits, (size_t)1, splits);   // the reference's fp32 row sum
+    if (reduction == 0) out[b] = scale * row;
+    acc += (double)row;
+  }
+  if (reduction == 0) return;
+  acc = block_sum(acc, scratch);
+  if (threadIdx.x == 0) out[0] = scale * (float)(reduction == 2 ? acc / (double)B : acc);
+}
+// d recon of the above: coefficient g[b] * scale (none) or g[0] * scale [/ B] (sum / mean)
+template <int LT>
+__global__ void recon_loss_bwd_kernel(const float* __restrict__ x, const float* __restrict__ recon,
+                                      const float* __restrict__ g, float* __restrict__ drecon, size_t P, size_t n,
+                                      int reduction, float coef) {
+  const float g0 = reduction ? g[0] * coef : 0.f;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    drecon[i] = (reduction ? g0 : g[i / P] * coef) * rec_derr<LT>(recon[i], x[i]);
+}
+
+// solvers/intro.py:102-103: out[0] = mean_j exp(c * (a[j] + b[j])), c = -2 * scale; w[j] = exp(...) * c / B kept for the
+// backward (d out / d a[j] = d out / d b[j] = w[j])
+__global__ __launch_bounds__(256) void exp_elbo_fwd_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                          float* __restrict__ out, float* __restrict__ w, int B, float c) {
+  __shared__ float scratch[4];
+  float acc = 0.f;
+  for (int j = threadIdx.x; j < B; j += 256) {
+    const float e = expf(c * (a[j] + b[j]));
+    w[j] = e * c / (float)B;
+    acc += e;
+  }
+  acc = block_sum(acc, scratch);
+  if (threadIdx.x == 0) out[0] = acc / (float)B;
+}
+__global__ void exp_elbo_bwd_kernel(const float* __restrict__ g, const float* __restrict__ w, float* __restrict__ da,
+                                    float* __restrict__ db, int B) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= B) return;
+  const float v = g[0] * w[j];
+  da[j] = v;
+  if (db) db[j] = v;
+}
+
+// out[0] = sum_k weight[k] * *term[k] (k < n <= 8): the scalar arithmetic of a solver's loss (solvers/intro.py:105-108,
+// 149-151; solvers/vae.py:106) in one launch; the backward writes grad[k] = g * weight[k]
+struct LinComb {
+  const float* term[8];
+  float weight[8];
+  int n;
+};
+__global__ void lincomb_fwd_kernel(LinComb a, float* __restrict__ out) {
+  if (threadIdx.x || blockIdx.x) return;
+  float s = 0.f;
+  for (int k = 0; k < a.n; ++k) s += a.weight[k] * a.term[k][0];
+  out[0] = s;
+}
+__global__ void lincomb_bwd_kernel(const float* __restrict__ g, LinComb a, float* __restrict__ grads) {
+  const int k = threadIdx.x;
+  if (k < a.n) grads[k] = g[0] * a.weight[k];
+}
+
 static inline int recon_splits(int B, size_t P) {
   int s = cdiv(1024, B);
   const size_t maxs = cdivz(P, 2048);
@@ -212,6 +279,84 @@ int itcv_recon_rows_bwd(const float* x, const float* recon, const float* g, floa
   else
     return fail("%s: unknown loss type %lld", "itcv_recon_rows_bwd", loss_type);
   ITCV_CHECK_LAUNCH("itcv_recon_rows_bwd");
+  return 0;
+}
+
+int itcv_recon_loss_fwd(const float* x, const float* recon, float* out, int B, size_t P, int loss_type, int reduction,
+                        float scale, void* ws, size_t ws_bytes, void* stream) {
+  ITCV_REQUIRE(x && recon && out && B > 0 && P > 0 && reduction >= 0 && reduction <= 2, "itcv_recon_loss_fwd");
+  const int splits = recon_splits(B, P);
+  ITCV_REQUIRE(ws && ws_bytes >= (size_t)B * splits * sizeof(double), "itcv_recon_loss_fwd(workspace)");
+  double* part = static_cast<double*>(ws);
+  dim3 grid(B, splits);
+  hipStream_t st = S(stream);
+  if (loss_type == ITCV_LOSS_MSE)
+    hipLaunchKernelGGL(recon_partial_kernel<ITCV_LOSS_MSE>, grid, dim3(256), 0, st, x, recon, part, P, splits);
+  else if (loss_type == ITCV_LOSS_L1)
+    hipLaunchKernelGGL(recon_partial_kernel<ITCV_LOSS_L1>, grid, dim3(256), 0, st, x, recon, part, P, splits);
+  else if (loss_type == ITCV_LOSS_BCE)
+    hipLaunchKernelGGL(recon_partial_kernel<ITCV_LOSS_BCE>, grid, dim3(256), 0, st, x, recon, part, P, splits);
+  else
+    return fail("%s: unknown loss type %lld", "itcv_recon_loss_fwd", loss_type);
+  ITCV_CHECK_LAUNCH("itcv_recon_loss_fwd");
+  hipLaunchKernelGGL(recon_finish_kernel, dim3(1), dim3(256), 0, st, part, out, B, splits, reduction, scale);
+  ITCV_CHECK_LAUNCH("itcv_recon_loss_fwd(finish)");
+  return 0;
+}
+
+int itcv_recon_loss_bwd(const float* x, const float* recon, const float* g, float* drecon, int B, size_t P, int loss_type,
+                        int reduction, float scale, void* stream) {
+  ITCV_REQUIRE(x && recon && g && drecon && B > 0 && P > 0 && reduction >= 0 && reduction <= 2, "itcv_recon_loss_bwd");
+  const size_t n = (size_t)B * P;
+  dim3 grid(stream_grid(n, 1));
+  hipStream_t st = S(stream);
+  const float coef = reduction == 2 ? scale / (float)B : scale;
+  if (loss_type == ITCV_LOSS_MSE)
+    hipLaunchKernelGGL(recon_loss_bwd_kernel<ITCV_LOSS_MSE>, grid, dim3(256), 0, st, x, recon, g, drecon, P, n, reduction, coef);
+  else if (loss_type == ITCV_LOSS_L1)
+    hipLaunchKernelGGL(recon_loss_bwd_kernel<ITCV_LOSS_L1>, grid, dim3(256), 0, st, x, recon, g, drecon, P, n, reduction, coef);
+  else if (loss_type == ITCV_LOSS_BCE)
+    hipLaunchKernelGGL(recon_loss_bwd_kernel<ITCV_LOSS_BCE>, grid, dim3(256), 0, st, x, recon, g, drecon, P, n, reduction, coef);
+  else
+    return fail("%s: unknown loss type %lld", "itcv_recon_loss_bwd", loss_type);
+  ITCV_CHECK_LAUNCH("itcv_recon_loss_bwd");
+  return 0;
+}
+
+int itcv_exp_elbo_fwd(const float* a, const float* b, float* out, float* w, int B, float c, void* stream) {
+  ITCV_REQUIRE(a && b && out && w && B > 0, "itcv_exp_elbo_fwd");
+  hipLaunchKernelGGL(exp_elbo_fwd_kernel, dim3(1), dim3(256), 0, S(stream), a, b, out, w, B, c);
+  ITCV_CHECK_LAUNCH("itcv_exp_elbo_fwd");
+  return 0;
+}
+int itcv_exp_elbo_bwd(const float* g, const float* w, float* da, float* db, int B, void* stream) {
+  ITCV_REQUIRE(g && w && da && B > 0, "itcv_exp_elbo_bwd");
+  hipLaunchKernelGGL(exp_elbo_bwd_kernel, dim3(cdiv(B, 256)), dim3(256), 0, S(stream), g, w, da, db, B);
+  ITCV_CHECK_LAUNCH("itcv_exp_elbo_bwd");
+  return 0;
+}
+
+int itcv_lincomb_fwd(const float* const* terms, const float* weights, int n, float* out, void* stream) {
+  ITCV_REQUIRE(terms && weights && out && n >= 1 && n <= 8, "itcv_lincomb_fwd");
+  LinComb a;
+  memset(&a, 0, sizeof(a));
+  a.n = n;
+  for (int k = 0; k < n; ++k) {
+    ITCV_REQUIRE(terms[k], "itcv_lincomb_fwd(term)");
+    a.term[k] = terms[k], a.weight[k] = weights[k];
+  }
+  hipLaunchKernelGGL(lincomb_fwd_kernel, dim3(1), dim3(64), 0, S(stream), a, out);
+  ITCV_CHECK_LAUNCH("itcv_lincomb_fwd");
+  return 0;
+}
+int itcv_lincomb_bwd(const float* g, const float* weights, int n, float* grads, void* stream) {
+  ITCV_REQUIRE(g && weights && grads && n >= 1 && n <= 8, "itcv_lincomb_bwd");
+  LinComb a;
+  memset(&a, 0, sizeof(a));
+  a.n = n;
+  for (int k = 0; k < n; ++k) a.weight[k] = weights[k];
+  hipLaunchKernelGGL(lincomb_bwd_kernel, dim3(1), dim3(64), 0, S(stream), g, a, grads);
+  ITCV_CHECK_LAUNCH("itcv_lincomb_bwd");
   return 0;
 }
 

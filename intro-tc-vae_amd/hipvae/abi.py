@@ -112,6 +112,10 @@ SIGNATURES = {
     "itcv_tc_fwd": (i32, [p, p, p, p, p, p, p, i32, i32, i32, i32, i64, i32, p, sz, p]),
     "itcv_tc_bwd_workspace": (sz, [i32, i32]),
     "itcv_tc_bwd": (i32, [p, p, p, p, p, p, p, p, p, p, i32, i32, i32, i32, i64, i32, p, sz, p]),
+    "itcv_tc_kl_fwd": (i32, [p] * 9 + [i32, i32, i32, i32, i64, f32, f32, i32, p, sz, p]),
+    "itcv_tc_kl_bwd": (i32, [p] * 10 + [i32, i32, i32, i32, i64, f32, f32, i32, p, sz, p]),
+    "itcv_kl_loss_fwd": (i32, [p, p, p, i32, i32, i32, f32, p]),
+    "itcv_kl_loss_bwd": (i32, [p, p, p, p, p, i32, i32, i32, f32, p]),
     "itcv_diag_logdensity_rows": (i32, [p, p, p, p, p, i32, i32, p]),
     "itcv_gauss_logdensity_fwd": (i32, [p, p, p, p, p, p, p, p, i32, p]),
     "itcv_gauss_logdensity_bwd": (i32, [p, p, p, p, p, p, p, p, p, p, i32, p]),
@@ -121,6 +125,12 @@ SIGNATURES = {
     "itcv_recon_workspace": (sz, [i32, sz]),
     "itcv_recon_rows_fwd": (i32, [p, p, p, i32, sz, i32, p, sz, p]),
     "itcv_recon_rows_bwd": (i32, [p, p, p, p, i32, sz, i32, p]),
+    "itcv_recon_loss_fwd": (i32, [p, p, p, i32, sz, i32, i32, f32, p, sz, p]),
+    "itcv_recon_loss_bwd": (i32, [p, p, p, p, i32, sz, i32, i32, f32, p]),
+    "itcv_exp_elbo_fwd": (i32, [p, p, p, p, i32, f32, p]),
+    "itcv_exp_elbo_bwd": (i32, [p, p, p, p, i32, p]),
+    "itcv_lincomb_fwd": (i32, [p, p, i32, p, p]),
+    "itcv_lincomb_bwd": (i32, [p, p, i32, p, p]),
     "itcv_sumsq_workspace": (sz, [sz]),
     "itcv_sumsq": (i32, [p, sz, p, p, sz, p]),
     "itcv_clip_coef": (i32, [p, i32, f64, p, p, p]),

@@ -978,6 +978,151 @@ class KlRowsFn(Function):
         return dlv, dmu
 
 
+_REDUCTION = {"none": 0, "sum": 1, "mean": 2}
+
+
+class KlLossFn(Function):
+    """scale * ops.kl_divergence(logvar, mu, reduce) (ops.py:136-163 + the hook's beta, solvers/vae.py:63-77): one launch."""
+
+    @staticmethod
+    def forward(ctx, logvar, mu, reduction, scale):
+        logvar, mu = _f32c(logvar), _f32c(mu)
+        B, D = logvar.shape
+        out = torch.empty((B,) if reduction == 0 else (), dtype=F32, device=mu.device)
+        call("itcv_kl_loss_fwd", ptr(logvar), ptr(mu), ptr(out), B, D, reduction, float(scale), stream())
+        ctx.save_for_backward(logvar, mu)
+        ctx.cfg = (B, D, reduction, float(scale))
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        logvar, mu = ctx.saved_tensors
+        B, D, reduction, scale = ctx.cfg
+        dlv, dmu = torch.empty_like(logvar), torch.empty_like(mu)
+        call("itcv_kl_loss_bwd", ptr(_f32c(g)), ptr(logvar), ptr(mu), ptr(dlv), ptr(dmu), B, D, reduction, scale, stream())
+        return dlv, dmu, None, None
+
+
+class TcKlFn(Function):
+    """coef_tc * total_correlation + coef_kl * kl_divergence with the hook's reduction (solvers/tc.py:69-89), fused into
+    the estimator's launches (forward: partials, finish [, reduce]; backward: rows, columns)."""
+
+    @staticmethod
+    def forward(ctx, z, mu_all, logvar, dataset_size, row_offset, coef_tc, coef_kl, reduction):
+        z, mu_all, logvar = _f32c(z), _f32c(mu_all), _f32c(logvar)
+        Bl, D = z.shape
+        Bt = mu_all.shape[0]
+        dev = z.device
+        out = torch.empty((Bl,) if reduction == 0 else (), dtype=F32, device=dev)
+        rows = torch.empty((Bl,), dtype=F32, device=dev) if reduction else None
+        prodm = torch.empty((Bl,), dtype=F32, device=dev)
+        logqz = torch.empty((Bl,), dtype=F32, device=dev)
+        lse = torch.empty((Bl, D), dtype=F32, device=dev)
+        sjoint = torch.empty((Bl, Bt), dtype=F32, device=dev)
+        nws = lib.itcv_tc_fwd_workspace(Bl, Bt, D)
+        ws = _ws(nws, dev)
+        call("itcv_tc_kl_fwd", ptr(z), ptr(mu_all), ptr(logvar), ptr(out), ptr(rows), ptr(prodm), ptr(logqz), ptr(lse),
+             ptr(sjoint), Bl, Bt, int(row_offset), D, int(dataset_size), float(coef_tc), float(coef_kl), reduction, ptr(ws),
+             nws, stream())
+        ctx.save_for_backward(z, mu_all, logvar, logqz, lse, sjoint)
+        ctx.cfg = (int(dataset_size), int(row_offset), float(coef_tc), float(coef_kl), reduction)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        z, mu_all, logvar, logqz, lse, sjoint = ctx.saved_tensors
+        n, off, ctc, ckl, reduction = ctx.cfg
+        Bl, D = z.shape
+        Bt = mu_all.shape[0]
+        dz, dlv, dmu = torch.empty_like(z), torch.empty_like(logvar), torch.empty_like(mu_all)
+        nws = lib.itcv_tc_bwd_workspace(Bl, Bt)
+        ws = _ws(nws, z.device)
+        call("itcv_tc_kl_bwd", ptr(_f32c(g)), ptr(z), ptr(mu_all), ptr(logvar), ptr(logqz), ptr(lse), ptr(sjoint), ptr(dz),
+             ptr(dmu), ptr(dlv), Bl, Bt, off, D, n, ctc, ckl, reduction, ptr(ws), nws, stream())
+        return dz, dmu, dlv, None, None, None, None, None
+
+
+class ReconLossFn(Function):
+    """scale * ops.reconstruction_loss(x, recon, loss_type, reduction) (ops.py:188-236 + the hook's beta): two launches
+    forward, one backward; x is a constant."""
+
+    @staticmethod
+    def forward(ctx, x, recon, loss_type, reduction, scale):
+        x, recon = _f32c(x), _f32c(recon)
+        B = recon.shape[0]
+        P = recon.numel() // B
+        out = torch.empty((B,) if reduction == 0 else (), dtype=F32, device=recon.device)
+        nws = lib.itcv_recon_workspace(B, P)
+        ws = _ws(nws, recon.device)
+        call("itcv_recon_loss_fwd", ptr(x), ptr(recon), ptr(out), B, P, loss_type, reduction, float(scale), ptr(ws), nws,
+             stream())
+        ctx.save_for_backward(x, recon)
+        ctx.cfg = (B, P, loss_type, reduction, float(scale))
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        x, recon = ctx.saved_tensors
+        B, P, lt, reduction, scale = ctx.cfg
+        d = torch.empty_like(recon)
+        call("itcv_recon_loss_bwd", ptr(x), ptr(recon), ptr(_f32c(g)), ptr(d), B, P, lt, reduction, scale, stream())
+        return None, d, None, None, None
+
+
+class ExpElboFn(Function):
+    """mean_j exp(c * (a_j + b_j)) (solvers/intro.py:102-103 with c = -2 * scale): one launch each way."""
+
+    @staticmethod
+    def forward(ctx, a, b, c):
+        a, b = _f32c(a), _f32c(b)
+        B = a.shape[0]
+        out = torch.empty((), dtype=F32, device=a.device)
+        w = torch.empty((B,), dtype=F32, device=a.device)
+        call("itcv_exp_elbo_fwd", ptr(a), ptr(b), ptr(out), ptr(w), B, float(c), stream())
+        ctx.save_for_backward(w)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        (w,) = ctx.saved_tensors
+        da, db = torch.empty_like(w), torch.empty_like(w)
+        call("itcv_exp_elbo_bwd", ptr(_f32c(g)), ptr(w), ptr(da), ptr(db), w.shape[0], stream())
+        return da, db, None
+
+
+class LinCombFn(Function):
+    """sum_k weights[k] * terms[k] over up to 8 device scalars: the scalar arithmetic of a solver's loss in one launch."""
+
+    @staticmethod
+    def forward(ctx, weights, *terms):
+        import ctypes
+        n = len(terms)
+        terms = [_f32c(t) for t in terms]
+        if any(t.numel() != 1 for t in terms):
+            raise abi.HipExtensionError("LinCombFn: every term must be a scalar")
+        out = torch.empty((), dtype=F32, device=terms[0].device)
+        tp = (ctypes.c_void_p * n)(*[ptr(t) for t in terms])
+        wp = (ctypes.c_float * n)(*[float(w) for w in weights])
+        call("itcv_lincomb_fwd", tp, wp, n, ptr(out), stream())
+        ctx.weights = [float(w) for w in weights]
+        ctx.shapes = [t.shape for t in terms]
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        import ctypes
+        n = len(ctx.weights)
+        grads = torch.empty((n,), dtype=F32, device=g.device)
+        wp = (ctypes.c_float * n)(*ctx.weights)
+        call("itcv_lincomb_bwd", ptr(_f32c(g)), wp, n, ptr(grads), stream())
+        return (None,) + tuple(grads[k].reshape(ctx.shapes[k]) for k in range(n))
+
+
 def tc_components(z, mu_all, logvar, dataset_size, row_offset=0, flags=abi.TC_LIVE, with_joint=False):
     """(prodm[Bl], logqz[Bl], lse[Bl,D]) of the fused pairwise-density / sampling kernel (+ the joint terms
     S[Bl,Bt] the backward reads, with ``with_joint``)."""

@@ -67,32 +67,24 @@ def kl_no_reduce(logvar, mu):
     return HF.KlRowsFn.apply(logvar, mu)
 
 
-def kl_divergence(logvar, mu, reduce="sum"):
-    """ops.py:136-158."""
-    kl = kl_no_reduce(logvar, mu)
-    if reduce == "sum":
-        kl = kl.sum()
-    elif reduce == "mean":
-        kl = kl.mean()
-    return kl
+def kl_divergence(logvar, mu, reduce="sum", scale=1.0):
+    """ops.py:136-158 (any ``reduce`` other than 'sum' / 'mean' returns the per-sample vector, as there), in ONE launch;
+    ``scale`` (extension) multiplies the result inside that launch -- the solver hooks pass their beta."""
+    return HF.KlLossFn.apply(logvar, mu, {"sum": 1, "mean": 2}.get(reduce, 0), float(scale))
 
 
-def reconstruction_loss(x, recon_x, loss_type="mse", reduction="sum"):
+def reconstruction_loss(x, recon_x, loss_type="mse", reduction="sum", scale=1.0):
     """ops.py:188-236; NotImplementedError for unknown loss_type / reduction, AssertionError on
-    an empty batch, x is detached."""
+    an empty batch, x is detached.  The reduction runs inside the kernels (two launches in all); ``scale`` (extension)
+    multiplies the result there -- the solver hooks pass their beta."""
     batch_size = x.size(0)
     assert batch_size != 0
     if reduction not in ("sum", "mean", "none"):
         raise NotImplementedError
     if loss_type not in abi.LOSS_TYPES:
         raise NotImplementedError
-    rows = HF.ReconRowsFn.apply(x.detach().reshape(x.size(0), -1), recon_x.reshape(recon_x.size(0), -1),
-                                abi.LOSS_TYPES[loss_type])
-    if reduction == "sum":
-        return rows.sum()
-    if reduction == "mean":
-        return rows.mean()
-    return rows
+    return HF.ReconLossFn.apply(x.detach().reshape(x.size(0), -1), recon_x.reshape(recon_x.size(0), -1),
+                                abi.LOSS_TYPES[loss_type], HF._REDUCTION[reduction], float(scale))
 
 
 def gaussian_log_density_torch(x, mu, logvar):
@@ -130,6 +122,14 @@ def total_correlation(z, mu, logvar, dataset_size, reduce="mean", mu_all=None, r
     whole global batch (all-gathered) and this rank's first global row."""
     tc = HF.TcRowsFn.apply(z, mu if mu_all is None else mu_all, logvar, int(dataset_size), int(row_offset))
     return tc.mean() if reduce == "mean" else tc
+
+
+def tc_kl_loss(z, mu, logvar, dataset_size, beta, reduce="mean", mu_all=None, row_offset=0):
+    """(beta - 1) * total_correlation(z, mu, logvar, N, reduce) + kl_divergence(logvar, mu, reduce): the KL hook of the TC
+    solvers (solvers/tc.py:69-89) fused into the estimator's launches (3 forward, 2 backward).  ``reduce`` as in the
+    reference: 'mean', else per sample."""
+    return HF.TcKlFn.apply(z, mu if mu_all is None else mu_all, logvar, int(dataset_size), int(row_offset), float(beta) - 1.0,
+                           1.0, 2 if reduce == "mean" else 0)
 
 
 def tc_components(z, mu, logvar, dataset_size, *, var_from_row=True, eps_density=True, weighted=False):

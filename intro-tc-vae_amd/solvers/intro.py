@@ -11,6 +11,7 @@ import torch
 from torch import Tensor
 
 from hipvae import ddp
+from hipvae.functional import ExpElboFn
 from models import bn_groups
 from ops import noise, reparameterize
 from solvers.vae import VAESolver
@@ -35,6 +36,8 @@ class IntroSolver(VAESolver):
         """intro.py:102-103  mean_j exp(-2 * scale * (rec_j + kl_j))."""
         while rec_rows.dim() > 1:
             rec_rows = rec_rows.sum(-1)
+        if rec_rows.is_cuda and rec_rows.shape == kl_rows.shape and rec_rows.dim() == 1:
+            return ExpElboFn.apply(rec_rows, kl_rows, -2 * self.scale)         # one launch each way
         return (-2 * self.scale * (rec_rows + kl_rows)).exp().mean()
 
     def _device_step(self, real: Tensor) -> Tensor:
@@ -68,7 +71,8 @@ class IntroSolver(VAESolver):
         kl_fake = self.compute_kl_loss(z_fake, fake_mu, fake_logvar, reduce="none", beta=self.beta_neg)
         expelbo_rec = self._exp_elbo(self.compute_rec_loss(rec, rec_rec, reduction="none"), kl_rec)
         expelbo_fake = self._exp_elbo(self.compute_rec_loss(fake, rec_fake, reduction="none"), kl_fake)
-        loss_e = scale * (loss_rec + loss_e_real_kl) + 0.25 * (expelbo_rec + expelbo_fake)
+        # scale * (loss_rec + loss_e_real_kl) + 0.25 * (expelbo_rec + expelbo_fake), intro.py:105-108
+        loss_e = self._lincomb((scale, scale, 0.25, 0.25), loss_rec, loss_e_real_kl, expelbo_rec, expelbo_fake)
         finish_average = self._backward(loss_e, ("encoder",), defer_average=True)
 
         # ================= update D (encoder frozen) ======================== intro.py:118-160
@@ -94,7 +98,9 @@ class IntroSolver(VAESolver):
         loss_fake_rec = self.compute_rec_loss(fake.detach(), rec_fake, reduction="mean", beta=g)
         loss_d_rec_kl = self.compute_kl_loss(z_rec, rec_mu, rec_logvar)
         loss_d_fake_kl = self.compute_kl_loss(z_fake, fake_mu, fake_logvar)
-        loss_d = scale * (loss_rec + (loss_d_rec_kl + loss_d_fake_kl) * 0.5 + (loss_rec_rec + loss_fake_rec) * 0.5)
+        # scale * (loss_rec + (kl_rec + kl_fake) * 0.5 + (rec_rec + fake_rec) * 0.5), intro.py:149-151
+        loss_d = self._lincomb((scale, 0.5 * scale, 0.5 * scale, 0.5 * scale, 0.5 * scale), loss_rec, loss_d_rec_kl,
+                               loss_d_fake_kl, loss_rec_rec, loss_fake_rec)
         self._backward(loss_d, ("decoder",))
         norm_d = self._clip()
         self._step("decoder")
@@ -124,7 +130,8 @@ class IntroSolver(VAESolver):
         kl_fake = self.compute_kl_loss(z_fake, fake_mu, fake_logvar, reduce="none", beta=self.beta_neg)
         expelbo_rec = self._exp_elbo(self.compute_rec_loss(rec, rec_rec, reduction="none"), kl_rec)
         expelbo_fake = self._exp_elbo(self.compute_rec_loss(fake, rec_fake, reduction="none"), kl_fake)
-        loss_e = scale * (loss_rec + loss_e_real_kl) + 0.25 * (expelbo_rec + expelbo_fake)
+        # scale * (loss_rec + loss_e_real_kl) + 0.25 * (expelbo_rec + expelbo_fake), intro.py:105-108
+        loss_e = self._lincomb((scale, scale, 0.25, 0.25), loss_rec, loss_e_real_kl, expelbo_rec, expelbo_fake)
         finish_average = self._backward(loss_e, ("encoder",), defer_average=True)
 
         # ================= update D (encoder frozen) ======================== intro.py:118-160
@@ -149,7 +156,9 @@ class IntroSolver(VAESolver):
         loss_fake_rec = self.compute_rec_loss(fake.detach(), rec_fake, reduction="mean", beta=g)
         loss_d_rec_kl = self.compute_kl_loss(z_rec, rec_mu, rec_logvar)
         loss_d_fake_kl = self.compute_kl_loss(z_fake, fake_mu, fake_logvar)
-        loss_d = scale * (loss_rec + (loss_d_rec_kl + loss_d_fake_kl) * 0.5 + (loss_rec_rec + loss_fake_rec) * 0.5)
+        # scale * (loss_rec + (kl_rec + kl_fake) * 0.5 + (rec_rec + fake_rec) * 0.5), intro.py:149-151
+        loss_d = self._lincomb((scale, 0.5 * scale, 0.5 * scale, 0.5 * scale, 0.5 * scale), loss_rec, loss_d_rec_kl,
+                               loss_d_fake_kl, loss_rec_rec, loss_fake_rec)
         self._backward(loss_d, ("decoder",))
         norm_d = self._clip()
         self._step("decoder")

@@ -6,7 +6,7 @@ from typing import Optional
 from torch import Tensor
 
 from hipvae import ddp
-from ops import kl_divergence, tc_decomposition, total_correlation
+from ops import kl_divergence, tc_decomposition, tc_kl_loss, total_correlation
 from solvers.vae import VAESolver
 from utils import SingletonWriter
 
@@ -23,11 +23,13 @@ class TCSovler(VAESolver):
         if beta is None:
             beta = self.beta_kl
         dataset_size = len(self.dataset)
+        if not (write and self.writer):       # the whole hook inside the estimator's own launches
+            return tc_kl_loss(z, mu, logvar, dataset_size, beta, reduce, mu_all=ddp.all_gather_rows(mu),
+                              row_offset=ddp.row_offset(mu.shape[0]))
         kl_loss = kl_divergence(logvar, mu, reduce=reduce)
         tc = total_correlation(z, mu, logvar, dataset_size, reduce=reduce, mu_all=ddp.all_gather_rows(mu),
                                row_offset=ddp.row_offset(mu.shape[0]))
-        if write:
-            self.write_scalar(SingletonWriter().cur_iter, "kl_loss_unscaled", kl_loss)
+        self.write_scalar(SingletonWriter().cur_iter, "kl_loss_unscaled", kl_loss)
         return (beta - 1.0) * tc + kl_loss
 
     def kl_decomposition(self, z, mu, logvar):

@@ -10,7 +10,7 @@ import torch
 from torch import Tensor
 
 from hipvae import ddp
-from hipvae.functional import conv_math_scope, direct_grad_accumulation
+from hipvae.functional import LinCombFn, conv_math_scope, direct_grad_accumulation
 from hipvae.flat import FlatGroup, clip_grad_norm, plain_adam_hparams
 from ops import kl_divergence, reconstruction_loss
 from utils import SingletonWriter
@@ -57,18 +57,28 @@ class VAESolver:
                         beta: float = None, write: bool = False) -> Tensor:
         if beta is None:
             beta = self.beta_kl
+        if not (write and self.writer):
+            return kl_divergence(logvar, mu, reduce=reduce, scale=beta)      # beta * kl inside the one launch
         kl = kl_divergence(logvar, mu, reduce=reduce)
-        if write:
-            self.write_scalar(SingletonWriter().cur_iter, "kl_loss_unscaled", kl)
+        self.write_scalar(SingletonWriter().cur_iter, "kl_loss_unscaled", kl)
         return beta * kl
 
     def compute_rec_loss(self, x, recon_x, reduction="sum", beta: float = None, write: bool = False) -> Tensor:
         if beta is None:
             beta = self.beta_rec
+        if not (write and self.writer):
+            return reconstruction_loss(x, recon_x, self.recon_loss_type, reduction, scale=beta)
         rec = reconstruction_loss(x, recon_x, self.recon_loss_type, reduction)
-        if write:
-            self.write_scalar(SingletonWriter().cur_iter, "r_loss_unscaled", rec)
+        self.write_scalar(SingletonWriter().cur_iter, "r_loss_unscaled", rec)
         return beta * rec
+
+    @staticmethod
+    def _lincomb(weights, *terms):
+        """sum_k weights[k] * terms[k] for scalar loss terms in one launch (overridden hooks that return anything but a
+        device scalar fall back to torch arithmetic)."""
+        if all(isinstance(t, Tensor) and t.numel() == 1 and t.is_cuda for t in terms):
+            return LinCombFn.apply(tuple(weights), *terms)
+        return sum(w * t for w, t in zip(weights, terms))
 
     # ---- optimiser tail shared by all solvers ----------------------------------------------
     def _params(self, part):
@@ -203,7 +213,7 @@ class VAESolver:
         mu, logvar, z, rec = self.model(real)
         loss_rec = self.compute_rec_loss(real, rec, reduction="mean", write=True)
         loss_kl = self.compute_kl_loss(z, mu, logvar, write=True)
-        loss = self.scale * (loss_rec + loss_kl)
+        loss = self._lincomb((self.scale, self.scale), loss_rec, loss_kl)      # scale * (loss_rec + loss_kl), vae.py:106
         self._backward(loss, ("decoder", "encoder"))
         norm = self._clip()
         self._step("encoder")
