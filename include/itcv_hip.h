@@ -133,6 +133,17 @@ size_t itcv_conv2d_wgrad_bf16p_workspace(int B, int Ci, int H, int W, int Co, in
 int itcv_conv2d_wgrad_bf16p(const void* xplanes, const void* dyplanes, float* dw, int B, int Ci, int H, int W,
                             int Co, int KS, int up2, int ns /* 2 or 4 */, int accumulate, void* ws, size_t ws_bytes,
                             void* stream);
+/* accumulate == 2 DEFERS the slab reduce of itcv_conv2d_wgrad_bf16p: the call leaves its itcv_conv2d_wgrad_bf16p_slabs(...)
+ * fp32 slabs in `ws` (which must then stay alive), and ONE itcv_wgrad_reduce_many launch folds the slabs of many layers
+ * into their dw (a whole backward pass: solvers/intro.py:109-116).  The caller fills a host array of n descriptors of
+ * itcv_wgrad_reduce_desc_bytes() each (returns the blocks the layer adds, < 0 on error; block0 = their running sum; up to
+ * four slab sources per dw, folded in the given order: a weight used by several passes of the backward), copies it to the
+ * device and launches with the total.  Results are bitwise those of the per-call reduces. */
+int itcv_conv2d_wgrad_bf16p_slabs(int B, int Ci, int H, int W, int Co, int KS);
+size_t itcv_wgrad_reduce_desc_bytes(void);
+int itcv_wgrad_reduce_desc(void* host_desc, const float* const* slabs, const int* splits, int nsrc, float* dw, int Co,
+                           int Ci, int accumulate, int block0);
+int itcv_wgrad_reduce_many(const void* dev_table, int n, int total_blocks, void* stream);
 /* nn.Linear(K -> N) at batch B (models.py:233,270) as skinny exact-fp32 MFMA GEMMs, in every conv-math mode:
  * y[B][N] = x[B][K] w[N][K]^T + bias;  dx[B][K] = dy[B][N] w;  dw[N][K] (+)= dy^T x.  Deterministic
  * split-K; itcv_linear_workspace serves all three. */

@@ -1709,6 +1709,36 @@ __global__ __launch_bounds__(256) void wgrad_p_reduce(const float* __restrict__ 
   }
 }
 
+// The same reduce for MANY layers in one launch (a backward pass's weight gradients, folded when the pass is over): a
+// device-resident table of descriptors, every layer owns a contiguous block range; a layer whose weight took part in
+// several network passes of the backward lists their slabs in call order -- the chain dw + a_0 + a_1 + ... + b_0 + ... is
+// exactly what the per-call reduces compute one after the other (bitwise equal).
+struct WgReduceDesc {
+  const float* slab[4];
+  float* dw;
+  int splits[4];
+  int nsrc, coci, accumulate, block0, nblocks, pad_;
+};
+static_assert(sizeof(WgReduceDesc) == 80, "WgReduceDesc layout is part of the ABI (itcv_wgrad_reduce_desc_bytes)");
+
+__global__ __launch_bounds__(256) void wgrad_p_reduce_many(const WgReduceDesc* __restrict__ tab, int n) {
+  __shared__ int s_cnt[4];
+  int mine = 0;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) mine += tab[i].block0 <= (int)blockIdx.x ? 1 : 0;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) mine += __shfl_down(mine, off);
+  if ((threadIdx.x & 63) == 0) s_cnt[threadIdx.x >> 6] = mine;
+  __syncthreads();
+  const WgReduceDesc d = tab[s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3] - 1];
+  const size_t total = (size_t)d.coci * 9, stride = (size_t)9 * d.coci;
+  for (size_t idx = (size_t)(blockIdx.x - d.block0) * 256 + threadIdx.x; idx < total; idx += (size_t)d.nblocks * 256) {
+    const int tp = (int)(idx / d.coci), e = (int)(idx - (size_t)tp * d.coci);
+    float acc = d.accumulate ? d.dw[(size_t)e * 9 + tp] : 0.f;
+    for (int k = 0; k < d.nsrc; ++k) acc = fold_strided(acc, d.slab[k] + (size_t)tp * d.coci + e, stride, d.splits[k]);
+    d.dw[(size_t)e * 9 + tp] = acc;
+  }
+}
+
 // Same reduce for SMALL weight tensors with many slices (the 5x5 layers: 4800 elements x 256 slices): one thread
 // per element would walk the slices as one long latency chain, so 16 threads share an element (slice s -> thread
 // s % 16, each in ascending order) and their partial sums are folded in a fixed order through LDS.
@@ -2617,11 +2647,47 @@ int itcv_conv2d_wgrad_bf16p(const void* xplanes, const void* dyplanes, float* dw
     }
   }
   ITCV_CHECK_LAUNCH("itcv_conv2d_wgrad_bf16p");
+  if (accumulate == 2) return 0;     // deferred: the slabs stay in `ws` for itcv_wgrad_reduce_many
   const int coci = Co * Ci;
   const size_t rthreads = (size_t)coci * 9;
   hipLaunchKernelGGL(wgrad_p_reduce, dim3((int)(cdivz(rthreads, 256) < 8192 ? cdivz(rthreads, 256) : 8192)), dim3(256), 0,
                      st, static_cast<const float*>(ws), dw, coci, p.splits * p.kh, accumulate);
   ITCV_CHECK_LAUNCH("itcv_conv2d_wgrad_bf16p(reduce)");
+  return 0;
+}
+
+// Deferred reduce of itcv_conv2d_wgrad_bf16p(accumulate = 2) calls: slabs per call = itcv_conv2d_wgrad_bf16p_slabs.
+int itcv_conv2d_wgrad_bf16p_slabs(int B, int Ci, int H, int W, int Co, int KS) {
+  if (!itcv_conv2d_wgrad_bf16p_supported(B, Ci, H, W, Co, KS)) return 0;
+  const WgPlanP p = plan_wgrad_p(B, Ci, H, W, Co);
+  return p.splits * p.kh;
+}
+size_t itcv_wgrad_reduce_desc_bytes(void) { return sizeof(WgReduceDesc); }
+int itcv_wgrad_reduce_desc(void* host_desc, const float* const* slabs, const int* splits, int nsrc, float* dw, int Co, int Ci,
+                           int accumulate, int block0) {
+  if (!(host_desc && slabs && splits && nsrc >= 1 && nsrc <= 4 && dw && Co > 0 && Ci > 0 && block0 >= 0)) {
+    fail("%s: bad argument (1..4 slab sources, dw, Co/Ci > 0, block0 >= 0)", "itcv_wgrad_reduce_desc");
+    return -1;
+  }
+  WgReduceDesc d;
+  memset(&d, 0, sizeof(d));
+  for (int k = 0; k < nsrc; ++k) {
+    if (!slabs[k] || splits[k] < 1) {
+      fail("%s: null slab or non-positive slice count", "itcv_wgrad_reduce_desc");
+      return -1;
+    }
+    d.slab[k] = slabs[k], d.splits[k] = splits[k];
+  }
+  d.nsrc = nsrc, d.dw = dw, d.coci = Co * Ci, d.accumulate = accumulate ? 1 : 0, d.block0 = block0;
+  const size_t blocks = cdivz((size_t)d.coci * 9, 256);
+  d.nblocks = (int)(blocks < 1024 ? blocks : 1024);
+  memcpy(host_desc, &d, sizeof(d));
+  return d.nblocks;
+}
+int itcv_wgrad_reduce_many(const void* dev_table, int n, int total_blocks, void* stream) {
+  ITCV_REQUIRE(dev_table && n > 0 && total_blocks > 0, "itcv_wgrad_reduce_many");
+  hipLaunchKernelGGL(wgrad_p_reduce_many, dim3(total_blocks), dim3(256), 0, S(stream), static_cast<const WgReduceDesc*>(dev_table), n);
+  ITCV_CHECK_LAUNCH("itcv_wgrad_reduce_many");
   return 0;
 }
 

@@ -364,10 +364,84 @@ def _tile_stats_of(x, B, G, HW):
     return stats, T // G, T
 
 
+# ---- deferred slab reduces of the planes weight gradients ------------------------------------------------------------
+# Inside deferred_wgrad_reduces() (the solvers wrap loss.backward() in it) a weight gradient that accumulates into an
+# existing .grad leaves its split-K slabs in a persistent buffer and is folded, together with all the other layers of the
+# backward pass, by ONE table-driven launch when the block ends (36 reduce launches per intro step -> 3).  Same summation
+# order as the per-call reduce: bitwise equal.  Slab buffers are kept per position in the backward's call sequence and the
+# device tables per sequence of (slab, target) pointers, so a steady-state step (and its hipGraph) allocates and copies
+# nothing.
+_DEFER = {"on": False, "pending": [], "pool": {}, "tables": {}}
+
+
+@contextlib.contextmanager
+def deferred_wgrad_reduces():
+    prev, _DEFER["on"] = _DEFER["on"], True
+    try:
+        yield
+    finally:
+        _DEFER["on"] = prev
+        if not prev:
+            flush_wgrad_reduces()
+
+
+def flush_wgrad_reduces():
+    pend = _DEFER["pending"]
+    if not pend:
+        return
+    import ctypes
+    # group the calls by target (a weight used by several network passes of the backward), keeping call order
+    groups = {}
+    for ws, dw, co, ci, slabs in pend:
+        groups.setdefault(dw.data_ptr(), [dw, co, ci, []])[3].append((ws, slabs))
+    key = tuple((k, tuple((w.data_ptr(), n) for w, n in g[3])) for k, g in groups.items())
+    tab = _DEFER["tables"].get(key)
+    if tab is None:
+        nb = lib.itcv_wgrad_reduce_desc_bytes()
+        descs, blocks = [], 0
+        for dw, co, ci, srcs in groups.values():
+            for c0 in range(0, len(srcs), 4):          # at most four slab sources per descriptor; later ones accumulate
+                part = srcs[c0:c0 + 4]
+                descs.append((dw, co, ci, part, 1))
+        host = (ctypes.c_uint8 * (nb * len(descs)))()
+        for i, (dw, co, ci, part, acc) in enumerate(descs):
+            sl = (ctypes.c_void_p * len(part))(*[w.data_ptr() for w, _ in part])
+            sp = (ctypes.c_int * len(part))(*[n for _, n in part])
+            got = lib.itcv_wgrad_reduce_desc(ctypes.byref(host, i * nb), sl, sp, len(part), dw.data_ptr(), co, ci, acc, blocks)
+            if got <= 0:
+                raise abi.HipExtensionError("itcv_wgrad_reduce_desc: " + abi.last_error())
+            blocks += got
+        # descriptors of one target that were split into several (> 4 sources) would race inside one launch
+        if len(descs) != len(groups):
+            raise abi.HipExtensionError("deferred weight-gradient reduce: more than four passes over one weight")
+        if len(_DEFER["tables"]) > 64:
+            _DEFER["tables"].clear()
+        tab = _DEFER["tables"][key] = (torch.frombuffer(bytearray(host), dtype=torch.uint8).to(pend[0][1].device), len(descs), blocks)
+    call("itcv_wgrad_reduce_many", ptr(tab[0]), tab[1], tab[2], stream())
+    pend.clear()
+
+
+def _defer_slab_buffer(nbytes, device):
+    """Persistent slab buffer for the next deferred call: one per position in the pending sequence (and size)."""
+    k = (len(_DEFER["pending"]), int(nbytes), str(device))
+    buf = _DEFER["pool"].get(k)
+    if buf is None:
+        buf = _DEFER["pool"][k] = torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)
+    return buf
+
+
 def conv_wgrad_planes(xp, dyp, B, Ci, H, W, Co, KS, up2, out=None, accumulate=False, ns=2):
     """Weight gradient from the pre-split planes of x and dy (two-plane formats; transposing-LDS-read kernel)."""
     dw = out if out is not None else torch.empty((Co, Ci, KS, KS), dtype=F32, device=xp.device)
     nws = lib.itcv_conv2d_wgrad_bf16p_workspace(B, Ci, H, W, Co, KS)
+    if _DEFER["on"] and out is not None and accumulate:
+        if sum(1 for p in _DEFER["pending"] if p[1].data_ptr() == dw.data_ptr()) >= 4:
+            flush_wgrad_reduces()
+        ws = _defer_slab_buffer(nws, xp.device)
+        call("itcv_conv2d_wgrad_bf16p", ptr(xp), ptr(dyp), ptr(dw), B, Ci, H, W, Co, KS, int(up2), int(ns), 2, ptr(ws), nws,
+             stream())
+        _DEFER["pending"].append((ws, dw, Co, Ci, lib.itcv_conv2d_wgrad_bf16p_slabs(B, Ci, H, W, Co, KS)))
+        return dw
     ws = _ws(nws, xp.device)
 
     call("itcv_conv2d_wgrad_bf16p", ptr(xp), ptr(dyp), ptr(dw), B, Ci, H, W, Co, KS, int(up2), int(ns), int(accumulate),

@@ -10,7 +10,7 @@ import torch
 from torch import Tensor
 
 from hipvae import ddp
-from hipvae.functional import LinCombFn, conv_math_scope, direct_grad_accumulation
+from hipvae.functional import LinCombFn, conv_math_scope, deferred_wgrad_reduces, direct_grad_accumulation
 from hipvae.flat import FlatGroup, clip_grad_norm, plain_adam_hparams
 from ops import kl_divergence, reconstruction_loss
 from utils import SingletonWriter
@@ -112,7 +112,9 @@ class VAESolver:
         groups = [self._group(p) for p in parts]
         for g in groups:
             g.zero_grad()
-        with direct_grad_accumulation():     # wgrad / BN / bias kernels add straight into the flat buffers
+        # wgrad / BN / bias kernels add straight into the flat buffers; the planes weight gradients' slab reduces of the whole
+        # backward pass are folded by one launch when it is over
+        with direct_grad_accumulation(), deferred_wgrad_reduces():
             loss.backward()
         if defer_average:
             pending = [ddp.average_async(g.flat_g) for g in groups]

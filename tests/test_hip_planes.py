@@ -354,6 +354,42 @@ def test_planes_weight_gradient(HF, case):
     assert torch.equal(dw, again)   # split-K slabs are reduced in a fixed order
 
 
+def test_deferred_weight_gradient_reduces_equal_immediate_ones(HF):
+    """hipvae.functional.deferred_wgrad_reduces: the slab reduces of a whole backward pass folded by ONE launch
+    (itcv_wgrad_reduce_many) are bitwise the per-call reduces -- several layers, a weight that two network passes of the
+    backward both add to (its slabs chained in call order), accumulation into existing gradients, and a second, identical
+    backward that reuses the persistent slab buffers and the cached device table."""
+    g = torch.Generator().manual_seed(3)
+    d = dev()
+    layers = [(2, 64, 16, 16, 64, False), (4, 128, 4, 4, 256, False), (2, 32, 32, 32, 48, True), (2, 64, 16, 16, 64, False)]
+    ops_ = []
+    for B, Ci, H, W, Co, up2 in layers:
+        hs, ws = (H // 2, W // 2) if up2 else (H, W)
+        xp = HF.split_planes(torch.randn(B, Ci, hs, ws, generator=g).to(d), 2)
+        dyp = HF.split_planes(torch.randn(B, Co, H, W, generator=g).to(d), 2)
+        ops_.append((xp, dyp, B, Ci, H, W, Co, 3, up2))
+    grads0 = [torch.randn(o[6], o[3], 3, 3, generator=g).to(d) for o in ops_[:3]]
+    targets = [0, 1, 2, 0]                       # the fourth call adds to the first layer's gradient again
+
+    def run(deferred):
+        gr = [t.clone() for t in grads0]
+        for _ in range(2):                       # two backward passes: the second one hits the pool / table caches
+            if deferred:
+                with HF.deferred_wgrad_reduces():
+                    for o, t in zip(ops_, targets):
+                        HF.conv_wgrad_planes(*o, out=gr[t], accumulate=True)
+                    assert len(HF._DEFER["pending"]) == 4
+                assert not HF._DEFER["pending"]
+            else:
+                for o, t in zip(ops_, targets):
+                    HF.conv_wgrad_planes(*o, out=gr[t], accumulate=True)
+        return gr
+
+    a, b = run(False), run(True)
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)
+
+
 @pytest.mark.parametrize("shape,pool", [((4, 64, 32, 32), False), ((4, 64, 32, 32), True), ((2, 16, 8, 8), False),
                                         ((8, 128, 16, 16), False)])
 def test_batchnorm_emits_planes(HF, shape, pool):
