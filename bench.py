@@ -64,7 +64,8 @@ CONFIGS = {
 HP = dict(beta_kl=0.5, beta_rec=0.75, beta_neg=512.0, gamma_r=1e-8, clip=100.0, lr=2e-4, dataset=10000)
 PEAK_F32_MFMA_TFLOPS = 157.3
 PEAK_BF16_MFMA_TFLOPS = 2500.0       # dense; a split product costs 3 (bf16x3) or 6 (bf16x6) bf16 MFMA products
-PMC_FILE = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+PMC_FILE = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
+PEAK_HBM_GBS = 8000.0                # HBM3E spec (MI355X_MICROARCH.md: 8 TB/s; ~6.3 TB/s reachable with a float4 copy)
 DTYPE = {"fp32": "f32", "bf16x3": "f32 in/out/accumulate, conv products on split-bf16 MFMA (bf16x3)",
          "bf16x6": "f32 in/out/accumulate, conv products on split-bf16 MFMA (bf16x6, fp32-class)",
          "f16x3": "f32 in/out/accumulate, conv products on split-fp16 MFMA (two scaled fp16 planes, 3 products, fp32-class)"}
@@ -153,13 +154,31 @@ def make_solver(wl, math, dev):
     return solver
 
 
-def roofline_of(records, math, steps, eager_elapsed, where):
-    """Dominant-kernel roofline from the live HIP-event records of the eager leg."""
-    buckets = {}
-    for label, flop, secs in records:
-        b = buckets.setdefault(label, [0, 0.0, 0.0])
+def _pmc(cfg_name, math):
+    """PMC record of this (workload, arithmetic) from profiles/r03_pmc_traffic.json, or (None, reason)."""
+    try:
+        pmc = json.load(open(PMC_FILE))
+    except Exception:  # noqa: BLE001
+        return None, "profiles/r03_pmc_traffic.json not found"
+    rec = pmc.get("configs", {}).get(cfg_name)
+    if not rec or rec.get("math") != math:
+        return None, f"no PMC record for workload {cfg_name} / {math}"
+    if pmc.get("csrc_sha256") != csrc_digest():
+        return None, ("stale: the kernel sources changed since profiles/r03_pmc_traffic.json was collected (csrc_sha256 "
+                      "differs) -- re-run tools/evidence.sh")
+    return rec, ""
+
+
+def roofline_of(records, math, steps, eager_elapsed, where, cfg_name="c2"):
+    """Dominant-kernel rooflines from the live HIP-event records of the eager leg: the matrix-core one over the conv /
+    weight-gradient launches (work = algorithmic FLOP) and -- "hbm" -- the HBM one over the BatchNorm apply passes (work =
+    algorithmic bytes)."""
+    hbm_names = ("bn_act_fwd_planes_kernel", "bn_bwd_apply_planes")
+    buckets, hbuckets = {}, {}
+    for label, work, secs in records:
+        b = (hbuckets if label.startswith(hbm_names) else buckets).setdefault(label, [0, 0.0, 0.0])
         b[0] += 1
-        b[1] += flop
+        b[1] += work
         b[2] += secs
     conv_time = sum(b[2] for b in buckets.values())
     conv_flop = sum(b[1] for b in buckets.values())
@@ -171,21 +190,15 @@ def roofline_of(records, math, steps, eager_elapsed, where):
         peak, peak_note = PEAK_BF16_MFMA_TFLOPS / products, f"2500 TFLOP/s dense {kind} MFMA / {products} {kind} products per fp32 product"
     else:
         peak, peak_note = PEAK_F32_MFMA_TFLOPS, "dense fp32 MFMA"
-    traffic, traffic_note = None, "no PMC record for this kernel / arithmetic"
-    try:   # HBM bytes per launch from the committed rocprofv3 --pmc passes over this same command (tools/pmc_summary.py)
-        pmc = json.load(open(PMC_FILE))
-        rec = pmc["kernels"].get(dom_label) if math == pmc.get("math") else None
-        if rec and pmc.get("csrc_sha256") != csrc_digest():
-            traffic_note = ("stale: the kernel sources changed since profiles/r02_pmc_traffic.json was collected "
-                            "(csrc_sha256 differs) -- re-run the --pmc passes")
-        elif rec:
-            traffic = rec["hbm_bytes_per_launch_fetch_x2"]
-            traffic_note = (f"{os.path.relpath(PMC_FILE, ROOT)}: (2*FETCH_SIZE + WRITE_SIZE)*1024 per launch, rocprofv3 --pmc, "
-                            f"separate passes, same kernel sources (csrc_sha256); raw (uncorrected) = {rec['hbm_bytes_per_launch_raw']}; "
-                            "algorithmic operand + result bytes per launch: B*H*W*(4*Ci + 4*Co) + packed weights (DESIGN.md section 6)")
-    except Exception:  # noqa: BLE001
-        pass
-    return {
+    pmc, why = _pmc(cfg_name, math)
+    traffic, traffic_note = None, why or "no PMC record for this kernel"
+    rec = pmc["kernels"].get(dom_label) if pmc else None
+    if rec:
+        traffic = rec["hbm_bytes_per_launch_fetch_x2"]
+        traffic_note = (f"{os.path.relpath(PMC_FILE, ROOT)} [{cfg_name}]: (2*FETCH_SIZE + WRITE_SIZE)*1024 per launch, rocprofv3 --pmc, "
+                        f"separate passes, same kernel sources (csrc_sha256); raw (uncorrected) = {rec['hbm_bytes_per_launch_raw']}; "
+                        "algorithmic operand + result bytes per launch: B*H*W*(4*Ci + 4*Co) + packed weights (DESIGN.md section 6)")
+    out = {
         "bound": "mfma", "kernel": dom_label, "achieved": round(achieved, 2), "peak": round(peak, 1),
         "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_note": traffic_note,
         "peak_note": peak_note, "launches_per_step": dom[0] / steps, "avg_launch_us": round(dom[2] / dom[0] * 1e6, 2),
@@ -200,6 +213,31 @@ def roofline_of(records, math, steps, eager_elapsed, where):
                     "include the end-of-kernel L2 write-back of the result, which rocprofv3's dispatch timestamps do not "
                     "(5-20 % shorter there)" + where,
     }
+    if hbuckets:
+        # the HBM-bound block of the step (BatchNorm: ~27 % of kernel time): its largest bucket against the HBM peak
+        hl, hb = max(hbuckets.items(), key=lambda kv: kv[1][2])
+        gbs = hb[1] / hb[2] * 1e-9
+        base = hl.split("<")[0]
+        htraffic, hnote = None, why or "no PMC record for this kernel"
+        hrec = pmc["kernels"].get(base) if pmc else None
+        # the rocprofv3 name carries no shape: the record's LARGEST launch of this kernel is this bucket's launch only if
+        # the bucket is the kernel's largest one (by algorithmic bytes per launch)
+        biggest = max((k for k in hbuckets if k.startswith(base + "<")), key=lambda k: hbuckets[k][1] / hbuckets[k][0])
+        if hrec and biggest == hl:
+            htraffic = hrec["max_launch"]["hbm_bytes_fetch_x2"]
+            hnote = (f"{os.path.relpath(PMC_FILE, ROOT)} [{cfg_name}]: the kernel's largest launch, (2*FETCH_SIZE + WRITE_SIZE)*1024 "
+                     "(the two passes paired by launch ordinal)")
+        elif hrec:
+            hnote = "the PMC record's largest launch of this kernel is another shape"
+        out["hbm"] = {"bound": "hbm", "kernel": hl, "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                      "frac": round(gbs / PEAK_HBM_GBS, 4), "traffic": htraffic, "traffic_note": hnote,
+                      "avg_launch_us": round(hb[2] / hb[0] * 1e6, 2), "launches_per_step": hb[0] / steps,
+                      "algorithmic_mb_per_launch": round(hb[1] / hb[0] * 1e-6, 2),
+                      "share_of_eager_step_time": round(sum(b[2] for b in hbuckets.values()) / eager_elapsed, 3),
+                      "note": "BatchNorm apply pass (reads the conv output [and its gradient] once more, writes the planes): "
+                              "achieved = algorithmic bytes / live HIP-event time; right behind its producer much of the "
+                              "input is served by the 256 MiB Infinity Cache, so `achieved` can exceed what HBM alone delivers"}
+    return out
 
 
 def measure(wl, math, dev, args, rank, world, sync, use_graph, ddp_on, with_h2d=False):
@@ -285,7 +323,7 @@ def measure(wl, math, dev, args, rank, world, sync, use_graph, ddp_on, with_h2d=
     where = (", immediately before the timed hipGraph-replay steps" if use_graph else
              ", immediately before the timed eager steps" if ddp_on else " (the timed region)")
     return dict(solver=solver, batches=batches, elapsed=elapsed, eager_elapsed=eager_elapsed, last=last, h2d=h2d,
-                roofline=roofline_of(records, math, args.steps, eager_elapsed, where))
+                roofline=roofline_of(records, math, args.steps, eager_elapsed, where, args.config))
 
 
 def main():

@@ -14,17 +14,19 @@ struct ProfRec {
 static bool g_prof_on = false;
 static std::vector<ProfRec> g_prof;
 
+static thread_local int g_prof_depth = 0;   // nested scopes (an entry point calling another one) belong to the outermost
 ProfScope::ProfScope(hipStream_t stream, int kind, int ks, int bm, int up2, int ns, double flop) : st(stream), slot(-1) {
-  if (!g_prof_on) return;
+  if (++g_prof_depth > 1 || !g_prof_on) return;
   ProfRec r;
   r.code = kind | (ks << 4) | (bm << 8) | (up2 << 16) | (ns << 20);
   r.flop = flop;
   if (hipEventCreate(&r.start) != hipSuccess || hipEventCreate(&r.stop) != hipSuccess) return;
   g_prof.push_back(r);
   slot = (int)g_prof.size() - 1;
-  g_prof_start = r.start, g_prof_stop = r.stop;   // consumed by the scope's launch_timed()
+  g_prof_start = r.start, g_prof_stop = r.stop;   // consumed by the scope's first launch_timed()
 }
 ProfScope::~ProfScope() {
+  if (--g_prof_depth > 0) return;
   if (slot >= 0 && g_prof_start) {   // nothing was launched through launch_timed(): drop the record
     (void)hipEventDestroy(g_prof[slot].start);
     (void)hipEventDestroy(g_prof[slot].stop);

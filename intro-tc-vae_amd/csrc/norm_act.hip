@@ -1006,7 +1006,7 @@ int itcv_bn_act_fwd(const float* x, const float* mean, const float* rstd, const 
     const size_t pstride = plane_stride ? plane_stride : (size_t)B * (C / 8) * (pool ? (H / 2) * (W / 2) : H * W);
 #define ITCV_FWD_PLANES(POOL_, NS_, F_)                                                                               \
   do {                                                                                                                \
-      hipLaunchKernelGGL((bn_act_fwd_planes_kernel<POOL_, NS_, false, true, F_>), grid, blk, 0, S(stream), x, mean, rstd, gamma, \
+      launch_timed((bn_act_fwd_planes_kernel<POOL_, NS_, false, true, F_>), grid, blk, 0, S(stream), x, mean, rstd, gamma, \
                          beta, skip, y, pl, B, C, H, W, slope, BnStatsIn{}, pstride, BnGrp{});                                   \
   } while (0)
 #define ITCV_FWD_PLANES_NS(POOL_)                                   \
@@ -1112,7 +1112,7 @@ static int bwd_apply_impl(const float* x, const float* dy, const float* mean, co
     u32x4* pl = static_cast<u32x4*>(dx_planes);
 #define ITCV_BWD_PLANES(MODE_, NS_, F_)                                                                          \
   do {                                                                                                           \
-      hipLaunchKernelGGL((bn_bwd_apply_planes<MODE_, NS_, false, true, F_>), grid, blk, 0, st, x, dy, mean, rstd, gamma, beta, \
+      launch_timed((bn_bwd_apply_planes<MODE_, NS_, false, true, F_>), grid, blk, 0, st, x, dy, mean, rstd, gamma, beta, \
                          skip, dsums, count, dx, dskip, pl, B, C, H, W, slope, wsh, BnBwdSumsIn{}, pstride, BnGrp{}, mx, nmx); \
   } while (0)
 #define ITCV_BWD_PLANES_NS(MODE_)                                   \
@@ -1185,6 +1185,11 @@ int itcv_bn_train_fwd(const float* x, const float* gamma, const float* beta, con
                       void* ws, size_t ws_bytes, size_t plane_stride, const float* tile_stats, int tiles, int tile_pitch,
                       int groups, void* stream) {
   ITCV_REQUIRE(x && gamma && beta && mean && rstd && (y || planes) && B > 0 && C > 0 && H > 0 && W > 0, "itcv_bn_train_fwd");
+  // roofline leg of bench.py: one event pair around the apply kernel (HBM-bound: its "work" is algorithmic bytes -- read
+  // x once more [+ skip], write the planes [+ the fp32 output])
+  const double px_out = (double)(groups > 1 ? groups : 1) * B * C * (pool ? H * W / 4 : H * W);
+  ProfScope bn_prof(S(stream), 13, ilog2_exact(W) >= 0 ? ilog2_exact(W) : 0, C / 8, pool ? 1 : 0, planes ? ns : 0,
+                    (double)(groups > 1 ? groups : 1) * B * C * H * W * 4.0 * (skip ? 2 : 1) + px_out * ((planes ? 4.0 : 0.0) + (y ? 4.0 : 0.0)));
   if (groups > 1) {
     // `groups` BatchNorm groups of B images each, stacked along the batch dimension of x / y / planes; mean / rstd are
     // [groups][C].  Small layers (one block per channel computes the statistics): ONE statistics launch that walks the
@@ -1219,7 +1224,7 @@ int itcv_bn_train_fwd(const float* x, const float* gamma, const float* beta, con
       const dim3 grid(grid_for(threads), 1, groups), blk(256);
       u32x4* pl = static_cast<u32x4*>(planes);
 #define ITCV_FWD_GRP2_K(POOL_, NS_, ST_, F_)                                                                              \
-  hipLaunchKernelGGL((bn_act_fwd_planes_kernel<POOL_, NS_, ST_, true, F_>), grid, blk, 0, S(stream), x, mean, rstd, gamma, beta, \
+  launch_timed((bn_act_fwd_planes_kernel<POOL_, NS_, ST_, true, F_>), grid, blk, 0, S(stream), x, mean, rstd, gamma, beta, \
                      skip, y, pl, B, C, H, W, slope, (ST_) ? stg : BnStatsIn{}, plane_stride, grp)
 #define ITCV_FWD_GRP2(POOL_, NS_, F_)                                  \
   do {                                                                 \
@@ -1260,7 +1265,7 @@ int itcv_bn_train_fwd(const float* x, const float* gamma, const float* beta, con
     u32x4* pl = static_cast<u32x4*>(planes);
 #define ITCV_FWD_GRP(POOL_, NS_, F_)                                                                                      \
   do {                                                                                                                    \
-      hipLaunchKernelGGL((bn_act_fwd_planes_kernel<POOL_, NS_, false, true, F_>), grid, blk, 0, S(stream), x, mean, rstd, gamma, \
+      launch_timed((bn_act_fwd_planes_kernel<POOL_, NS_, false, true, F_>), grid, blk, 0, S(stream), x, mean, rstd, gamma, \
                          beta, skip, y, pl, B, C, H, W, slope, BnStatsIn{}, plane_stride, grp);                             \
   } while (0)
 #define ITCV_FWD_GRP_NS(POOL_)                                     \
@@ -1305,7 +1310,7 @@ int itcv_bn_train_fwd(const float* x, const float* gamma, const float* beta, con
   u32x4* pl = static_cast<u32x4*>(planes);
 #define ITCV_FWD_FUSED(POOL_, NS_, F_)                                                                               \
   do {                                                                                                                \
-      hipLaunchKernelGGL((bn_act_fwd_planes_kernel<POOL_, NS_, true, true, F_>), grid, blk, 0, S(stream), x, mean, rstd, gamma, \
+      launch_timed((bn_act_fwd_planes_kernel<POOL_, NS_, true, true, F_>), grid, blk, 0, S(stream), x, mean, rstd, gamma, \
                          beta, skip, y, pl, B, C, H, W, slope, st, pstride, BnGrp{});                                            \
   } while (0)
 #define ITCV_FWD_FUSED_NS(POOL_)                                     \
@@ -1329,6 +1334,11 @@ int itcv_bn_train_bwd(const float* x, const float* dy, const float* mean, const 
   ITCV_REQUIRE(x && dy && mean && rstd && gamma && beta && dsums && (dx || dx_planes) && B > 0 && C > 0,
                "itcv_bn_train_bwd");
   ITCV_REQUIRE(!(pool && up2), "itcv_bn_train_bwd(pool and up2 are exclusive)");
+  // roofline leg of bench.py: the apply kernel reads x and dy once more and writes the planes [+ fp32 dx, + dskip]
+  const double bn_el = (double)(groups > 1 ? groups : 1) * B * C * H * W;
+  ProfScope bn_prof(S(stream), 14, ilog2_exact(W) >= 0 ? ilog2_exact(W) : 0, C / 8, pool ? 1 : (up2 ? 2 : 0), dx_planes ? ns : 0,
+                    bn_el * 4.0 * (1.0 + (pool ? 0.25 : (up2 ? 4.0 : 1.0)) + (skip ? 1.0 : 0.0)) +
+                        bn_el * ((dx_planes ? 4.0 : 0.0) + (dx ? 4.0 : 0.0) + (dskip ? 4.0 : 0.0)));
   if (groups > 1) {   // see itcv_bn_train_fwd; dsums is [groups][2C], the parameter gradients add up over the groups
     ITCV_REQUIRE(!dx_planes || plane_stride, "itcv_bn_train_bwd(groups need the plane stride of the whole tensor)");
     const int HWg = H * W;
@@ -1357,7 +1367,7 @@ int itcv_bn_train_bwd(const float* x, const float* dy, const float* mean, const 
       const bool fold_in_apply = HWg / 4 >= 64;   // the apply pass folds the partial sums itself
       const BnBwdSumsIn smg{part, gsplits, dsums, dgamma, dbeta, accumulate};
 #define ITCV_BWD_GRP2_K(MODE_, NS_, SUMS_, F_)                                                                           \
-  hipLaunchKernelGGL((bn_bwd_apply_planes<MODE_, NS_, SUMS_, true, F_>), agrid, blk, 0, st, x, dy, mean, rstd, gamma, beta, \
+  launch_timed((bn_bwd_apply_planes<MODE_, NS_, SUMS_, true, F_>), agrid, blk, 0, st, x, dy, mean, rstd, gamma, beta, \
                      skip, (SUMS_) ? static_cast<const double*>(nullptr) : dsums, count, dx, dskip, pl, B, C, H, W, slope, \
                      wsh, (SUMS_) ? smg : BnBwdSumsIn{}, plane_stride, grp, mx, nmx)
 #define ITCV_BWD_GRP2(MODE_, NS_, F_)                                                                                    \
@@ -1410,7 +1420,7 @@ int itcv_bn_train_bwd(const float* x, const float* dy, const float* mean, const 
   do {                                                                                                                   \
     hipLaunchKernelGGL((bn_bwd_partial_v4<MODE_, true, F_>), rgrid, dim3(kRedThreads), 0, st, x, dy, mean, rstd, gamma, beta, \
                        skip, static_cast<double*>(nullptr), B, C, H, W, slope, 1, wsh, hwsh, bf, grp, mx, nmx);          \
-      hipLaunchKernelGGL((bn_bwd_apply_planes<MODE_, NS_, false, true, F_>), agrid, blk, 0, st, x, dy, mean, rstd, gamma, beta, \
+      launch_timed((bn_bwd_apply_planes<MODE_, NS_, false, true, F_>), agrid, blk, 0, st, x, dy, mean, rstd, gamma, beta, \
                          skip, dsums, count, dx, dskip, pl, B, C, H, W, slope, wsh, BnBwdSumsIn{}, plane_stride, grp, mx, nmx); \
   } while (0)
 #define ITCV_BWD_GRP_NS(MODE_)                          \
@@ -1458,7 +1468,7 @@ int itcv_bn_train_bwd(const float* x, const float* dy, const float* mean, const 
   do {                                                                                                                \
     hipLaunchKernelGGL((bn_bwd_partial_v4<MODE_, false, F_>), rgrid, dim3(kRedThreads), 0, st, x, dy, mean, rstd, gamma, \
                        beta, skip, part, B, C, H, W, slope, splits, wsh, hwsh, BnBwdFinal{}, BnGrp{}, mx, nmx);       \
-      hipLaunchKernelGGL((bn_bwd_apply_planes<MODE_, NS_, true, true, F_>), agrid, blk, 0, st, x, dy, mean, rstd, gamma, beta, \
+      launch_timed((bn_bwd_apply_planes<MODE_, NS_, true, true, F_>), agrid, blk, 0, st, x, dy, mean, rstd, gamma, beta, \
                          skip, static_cast<const double*>(nullptr), count, dx, dskip, pl, B, C, H, W, slope, wsh, sm,   \
                          pstride, BnGrp{}, mx, nmx);                                                                  \
   } while (0)

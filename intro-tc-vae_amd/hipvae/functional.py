@@ -463,7 +463,9 @@ class LaunchProfile:
     KINDS = {0: "conv_fwd_kernel", 1: "conv_fwd_bf16s_kernel", 2: "conv_wgrad_kernel", 3: "conv_wgrad_bf16s_kernel",
              4: "conv_small_cout_kernel", 5: "conv_small_cin_kernel", 6: "conv_fwd_bf16p_kernel",
              7: "conv_wgrad_bf16p_kernel", 8: "conv_fwd_bf16p2_kernel", 9: "conv_fwd_bf16p3_kernel",
-             10: "conv_small_cout_planes_kernel", 11: "conv_small_cin_mfma_kernel", 12: "conv_wgrad5_planes_kernel"}
+             10: "conv_small_cout_planes_kernel", 11: "conv_small_cin_mfma_kernel", 12: "conv_wgrad5_planes_kernel",
+             13: "bn_act_fwd_planes_kernel", 14: "bn_bwd_apply_planes"}
+    HBM_KINDS = (13, 14)     # HBM-bound kernels: the record's "work" is algorithmic BYTES, not FLOP
 
     @classmethod
     def begin(cls):
@@ -486,6 +488,8 @@ class LaunchProfile:
                 label = f"{cls.KINDS[kind]}<LOG2W={ks},BM={bm},up2={up2},NS={ns}>"
             elif kind in (1, 3, 6):
                 label = f"{cls.KINDS[kind]}<KS={ks},BM={bm},up2={up2},NS={ns}>"
+            elif kind in cls.HBM_KINDS:    # BatchNorm apply passes: channels, image width, pool / adjoint mode, plane format
+                label = f"{cls.KINDS[kind]}<C={8 * bm},W={1 << ks},mode={(c >> 16) & 15},NS={ns}>"
             elif kind in (10, 11, 12):     # the 5x5 layers on the matrix cores: C = the narrow side's channels
                 label = f"{cls.KINDS[kind]}<KS={ks},C={bm},stem={up2},NS={ns}>"
             else:

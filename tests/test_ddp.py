@@ -297,7 +297,7 @@ def _c2_worker(rank, world, port, out, math):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("math", ["fp32", "bf16x3"])
+@pytest.mark.parametrize("math", ["fp32", "f16x3", "bf16x3"])
 def test_ddp_c2_shape_step_vs_oracle(math):
     """Two processes x 4 images, Sync-BN, all-gathered means for the TC estimator, averaged gradients == the oracle's
     single-process step on the 8 images: returned scalars, every image / encoder output of the local rows, the
