@@ -425,6 +425,86 @@ def test_reconstruction(HF):
     assert rel_err(ops.reconstruction_loss(a.to(d), b.to(d), "mse", "none"), ref) < 1e-6
 
 
+def test_fused_loss_heads_equal_the_reference_expression_trees(HF):
+    """Round 3's one-launch loss heads against the expression trees they replace, built in fp64 from torch primitives the
+    way the reference's hooks / solver build them (solvers/vae.py:63-91, solvers/tc.py:69-89, solvers/intro.py:100-170):
+    beta * kl_divergence, beta * reconstruction_loss, (beta-1) TC + KL, mean exp(-2 s (rec + kl)), the scalar linear
+    combinations -- values and gradients, 1e-5 relative (TC term: the 1e-4 of the estimator's own golden test)."""
+    import ops
+    from oracle import latent_math as OM
+    d = dev()
+    g = torch.Generator().manual_seed(21)
+    B, D = 16, 24
+    mu, lv = torch.randn(B, D, generator=g), 0.7 * torch.randn(B, D, generator=g) - 0.5
+    z = mu + torch.exp(0.5 * lv) * torch.randn(B, D, generator=g)
+    w = torch.linspace(-1.0, 2.0, B)
+
+    def kl_ref(l, m, red):
+        rows = -0.5 * (1 + l - m.pow(2) - l.exp()).sum(1)
+        return {"sum": rows.sum(), "mean": rows.mean()}.get(red, rows)
+
+    for red in ("sum", "mean", "none"):
+        for scale in (1.0, 0.37, 512.0):
+            mm, ll = (t.clone().to(d).requires_grad_(True) for t in (mu, lv))
+            out = ops.kl_divergence(ll, mm, red, scale=scale)
+            mr, lr = (t.clone().double().requires_grad_(True) for t in (mu, lv))
+            ref = scale * kl_ref(lr, mr, red)
+            ((out * w.to(d)).sum() if red == "none" else out).backward()
+            ((ref * w.double()).sum() if red == "none" else ref).backward()
+            assert rel_err(out, ref) < 1e-5 and rel_err(mm.grad, mr.grad) < 1e-5 and rel_err(ll.grad, lr.grad) < 1e-5
+    x, xr = torch.rand(B, 3, 8, 8, generator=g), torch.rand(B, 3, 8, 8, generator=g) * 0.98 + 0.01
+    for lt in ("mse", "l1", "bce"):
+        for red in ("sum", "mean", "none"):
+            xg = xr.clone().to(d).requires_grad_(True)
+            out = ops.reconstruction_loss(x.to(d), xg, lt, red, scale=0.25)
+            rg = xr.clone().double().requires_grad_(True)
+            a, b = x.double().reshape(B, -1), rg.reshape(B, -1)
+            rows = {"mse": lambda: ((a - b) ** 2).sum(1), "l1": lambda: (a - b).abs().sum(1),
+                    "bce": lambda: -(a * b.log() + (1 - a) * (1 - b).log()).sum(1)}[lt]()
+            ref = 0.25 * {"sum": rows.sum(), "mean": rows.mean()}.get(red, rows)
+            ((out * w.to(d)).sum() if red == "none" else out).backward()
+            ((ref * w.double()).sum() if red == "none" else ref).backward()
+            assert rel_err(out, ref) < 1e-5 and rel_err(xg.grad, rg.grad) < 1e-5, (lt, red)
+    # (beta - 1) TC + KL, the TC solvers' hook, both reductions, also sharded over the rows (mu_all + row_offset)
+    N = 5000
+    for beta in (512.0, 0.5):
+        for red in ("mean", "none"):
+            zz, mm, ll = (t.clone().to(d).requires_grad_(True) for t in (z, mu, lv))
+            out = ops.tc_kl_loss(zz, mm, ll, N, beta, red)
+            zr, mr, lr = (t.clone().double().requires_grad_(True) for t in (z, mu, lv))
+            a, b = OM.stratified(OM.log_density_clamped_var(zr.unsqueeze(1), mr.unsqueeze(0), lr.unsqueeze(1)), N)
+            tc = b - a
+            ref = (beta - 1.0) * (tc.mean() if red == "mean" else tc) + kl_ref(lr, mr, red)
+            ((out * w.to(d)).sum() if red == "none" else out).backward()
+            ((ref * w.double()).sum() if red == "none" else ref).backward()
+            assert rel_err(out, ref) < 1e-4, (beta, red)
+            assert rel_err(zz.grad, zr.grad) < 1e-4 and rel_err(mm.grad, mr.grad) < 1e-4 and rel_err(ll.grad, lr.grad) < 1e-4
+            if red == "none":
+                parts = [ops.tc_kl_loss(z[r * 8:(r + 1) * 8].to(d), mu[r * 8:(r + 1) * 8].to(d), lv[r * 8:(r + 1) * 8].to(d), N,
+                                        beta, red, mu_all=mu.to(d), row_offset=r * 8) for r in range(2)]
+                assert rel_err(torch.cat(parts), out) < 1e-6
+    # solvers/intro.py:102-103: exp(-2 s (rec + beta kl)).mean()
+    a, b = 30.0 * torch.rand(B, generator=g), 5.0 * torch.rand(B, generator=g)
+    for c in (-2.0 / 12288, -0.05):
+        ag, bg = (t.clone().to(d).requires_grad_(True) for t in (a, b))
+        out = HF.ExpElboFn.apply(ag, bg, c)
+        ar, br = (t.clone().double().requires_grad_(True) for t in (a, b))
+        ref = torch.exp(c * (ar + br)).mean()
+        (3.0 * out).backward()
+        (3.0 * ref).backward()
+        assert rel_err(out, ref) < 1e-6 and rel_err(ag.grad, ar.grad) < 1e-5 and rel_err(bg.grad, br.grad) < 1e-5
+    # the solver's scalar algebra: sum_k w_k t_k, gradient w_k * g for every term
+    terms = [torch.randn((), generator=g) for _ in range(5)]
+    wts = [0.5, -1.25, 3.0, 1.0 / 12288, 0.0]
+    tg = [t.clone().to(d).requires_grad_(True) for t in terms]
+    out = HF.LinCombFn.apply(wts, *tg)
+    (2.0 * out).backward()
+    assert rel_err(out, sum(wk * t.double() for wk, t in zip(wts, terms))) < 1e-6
+    assert [float(t.grad) for t in tg] == pytest.approx([2.0 * wk for wk in wts], rel=1e-6, abs=1e-12)
+    with pytest.raises(Exception):
+        HF.LinCombFn.apply([1.0], torch.zeros(2, device=d))
+
+
 def test_ops_shapes_like_reference_tests():
     """Shape checks of the reference's tests/test_ops.py:48-66 on the HIP path."""
     import ops
