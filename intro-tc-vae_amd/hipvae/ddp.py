@@ -125,7 +125,8 @@ def graph_capturable():
     one-GPU development box only reaches a group of one rank (tests/test_ddp.py)."""
     import os
     c = get()
-    return (c is not None and dist.get_backend(c.group) == "nccl"
+    # no _wait_for_pending_works (another torch build): no way to wait for the watchdog's list to empty -> stay eager
+    return (c is not None and dist.get_backend(c.group) == "nccl" and hasattr(c.group, "_wait_for_pending_works")
             and os.environ.get("ITCV_DDP_GRAPH", "0") == "1")
 
 
