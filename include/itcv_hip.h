@@ -144,6 +144,7 @@ size_t itcv_wgrad_reduce_desc_bytes(void);
 int itcv_wgrad_reduce_desc(void* host_desc, const float* const* slabs, const int* splits, int nsrc, float* dw, int Co,
                            int Ci, int accumulate, int block0);
 int itcv_wgrad_reduce_many(const void* dev_table, int n, int total_blocks, void* stream);
+int itcv_wgrad_reduce_max_descs(void);   /* descriptors one table (one launch) may hold */
 /* nn.Linear(K -> N) at batch B (models.py:233,270) as skinny exact-fp32 MFMA GEMMs, in every conv-math mode:
  * y[B][N] = x[B][K] w[N][K]^T + bias;  dx[B][K] = dy[B][N] w;  dw[N][K] (+)= dy^T x.  Deterministic
  * split-K; itcv_linear_workspace serves all three. */

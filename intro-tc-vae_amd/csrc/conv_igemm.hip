@@ -1632,18 +1632,26 @@ __global__ __launch_bounds__(256) void conv_wgrad5_planes_kernel(const float* __
           const uint32_t ad = rbase + (uint32_t)(((pl * 8 + 2 * nt + (pp >> 1)) * PXS + w0 + 8 * kg + q) * 16 + (pp & 1) * 8);
           tr_read8(bfr[nt][pl], ad, ad + 64);
         }
+      // A fragments: S[b][cs][h + SG*(dh-2)][w0 + 8*kg + j + SG*(dw-2)], j = 0..7.  The 40 loads of the five filter rows
+      // go out together, from clamped (always valid) addresses, and are masked afterwards: loaded under their bounds
+      // checks, filter row by filter row, they were five dependent L2 round trips per 32 pixels.
+      float sv[5][8];
+      const int ws0 = seg + w0 + 8 * kg + SG * (dw - 2);
+      const float* spc = sm + ((size_t)b * CS + (row_used ? cs : 0)) * HW;
 #pragma unroll
       for (int dh = 0; dh < 5; ++dh) {
-        // A fragment: S[b][cs][h + SG*(dh-2)][w0 + 8*kg + j + SG*(dw-2)], j = 0..7
-        const int hs = h + SG * (dh - 2), ws0 = seg + w0 + 8 * kg + SG * (dw - 2);
+        const int hs = h + SG * (dh - 2);
+        const float* sp = spc + (size_t)min(max(hs, 0), H - 1) * W;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) sv[dh][j] = sp[min(max(ws0 + j, 0), W - 1)];
+      }
+#pragma unroll
+      for (int dh = 0; dh < 5; ++dh) {
+        const int hs = h + SG * (dh - 2);
         float v[8];
         const bool hok = row_used && (unsigned)hs < (unsigned)H;
-        const float* sp = sm + ((size_t)b * CS + (row_used ? cs : 0)) * HW + (size_t)(hok ? hs : 0) * W;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const int ww = ws0 + j;
-          v[j] = (hok && (unsigned)ww < (unsigned)W) ? sp[ww] : 0.f;
-        }
+        for (int j = 0; j < 8; ++j) v[j] = (hok && (unsigned)(ws0 + j) < (unsigned)W) ? sv[dh][j] : 0.f;
         u32x4 ap[2];
         split8<2, F16>(v, ap, sscale);
         const bf16x8 a0 = __builtin_bit_cast(bf16x8, ap[0]), a1 = __builtin_bit_cast(bf16x8, ap[1]);
@@ -1681,7 +1689,14 @@ __global__ __launch_bounds__(256) void wgrad5_reduce(const float* __restrict__ s
   if (i < total) {
     const int cb = i & 63, r = i >> 6, dh = r % 5, m = r / 5, cs = m / 5, dwi = m - cs * 5;
     const float* p = slab + (size_t)((m * 5 + dh) * 64 + cb);
-    for (int k = g; k < njobs; k += 16) s += p[(size_t)k * (16 * 5 * 64)];
+    // eight jobs' loads in flight (clamped index + select: no branch between the loads); job order per thread unchanged
+    for (int k = g; k < njobs; k += 16 * 8) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = p[(size_t)min(k + 16 * u, njobs - 1) * (16 * 5 * 64)];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += (k + 16 * u < njobs) ? v[u] : 0.f;
+    }
     dst = stem ? ((cb * CS + cs) * 5 + dh) * 5 + dwi : ((cs * 64 + cb) * 5 + dh) * 5 + dwi;
   }
   part[g][e] = s;
@@ -1704,24 +1719,91 @@ struct WgReduceDesc {
   const float* slab[4];
   float* dw;
   int splits[4];
-  int nsrc, coci, accumulate, block0, nblocks, pad_;
+  int nsrc, coci, accumulate, block0, nblocks, fine;   // fine: wgrad_reduce_tile_fine
 };
 static_assert(sizeof(WgReduceDesc) == 80, "WgReduceDesc layout is part of the ABI (itcv_wgrad_reduce_desc_bytes)");
 
-__device__ __forceinline__ void wgrad_reduce_tile(const WgReduceDesc& d, int tile, float (*part)[9][64]) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int e0 = tile * 64, e = e0 + lane;
-  const bool live = e < d.coci;
-  const size_t stride = (size_t)9 * d.coci;
-  float tot[3];
+// "Wide" tiles (layers with few slices): a thread owns FOUR consecutive (co, ci) elements x the 9 taps and walks all
+// slices itself, two slices (18 float4 loads) in flight -- no LDS, no barrier, and its 36 results are one contiguous
+// 144-byte run of dw.  The first form of this fold (64 elements x 9 taps per block, the four waves taking quarters of the
+// slice range, exchange through LDS) had a few KB in flight per block and idle phases around its barriers: ~2 TB/s whatever
+// the tiling (tools/reduce_bench.py).
+__device__ __forceinline__ void wgrad_reduce_tile(const WgReduceDesc& d, int tile) {
+  const int e = (tile * 256 + (int)threadIdx.x) * 4;
+  if (e >= d.coci) return;                                   // Co * Ci % 4 == 0 (Ci % 32 == 0)
+  const size_t plane = (size_t)d.coci, stride = 9 * plane;
+  float* dwp = d.dw + (size_t)e * 9;                         // 36 consecutive floats: (element i, tap tp) at i*9 + tp
+  const bool vec = ((size_t)dwp & 15) == 0;                  // (a gradient view inside a flat buffer may be 4-byte aligned only)
+  float tot[36];
+  if (d.accumulate) {
+    if (vec) {
 #pragma unroll
-  for (int j = 0; j < 3; ++j) {
-    const int o = threadIdx.x + j * 256;
-    tot[j] = (d.accumulate && o < 576 && e0 * 9 + o < d.coci * 9) ? d.dw[(size_t)e0 * 9 + o] : 0.f;
+      for (int q = 0; q < 9; ++q) {
+        const float4 t = reinterpret_cast<const float4*>(dwp)[q];
+        tot[4 * q] = t.x, tot[4 * q + 1] = t.y, tot[4 * q + 2] = t.z, tot[4 * q + 3] = t.w;
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < 36; ++q) tot[q] = dwp[q];
+    }
+  } else {
+#pragma unroll
+    for (int q = 0; q < 36; ++q) tot[q] = 0.f;
   }
   for (int k = 0; k < d.nsrc; ++k) {
-    const int q = (d.splits[k] + 3) >> 2;
-    const int s0 = wave * q, s1 = min(s0 + q, d.splits[k]);
+    const float* p = d.slab[k] + e;
+    float acc[36];
+#pragma unroll
+    for (int q = 0; q < 36; ++q) acc[q] = 0.f;
+    int sl = 0;
+    for (; sl + 2 <= d.splits[k]; sl += 2) {
+      float4 v[2][9];
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int tp = 0; tp < 9; ++tp) v[u][tp] = *reinterpret_cast<const float4*>(p + (size_t)(sl + u) * stride + (size_t)tp * plane);
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int tp = 0; tp < 9; ++tp)
+          acc[tp] += v[u][tp].x, acc[9 + tp] += v[u][tp].y, acc[18 + tp] += v[u][tp].z, acc[27 + tp] += v[u][tp].w;
+    }
+    if (sl < d.splits[k]) {
+      float4 v[9];
+#pragma unroll
+      for (int tp = 0; tp < 9; ++tp) v[tp] = *reinterpret_cast<const float4*>(p + (size_t)sl * stride + (size_t)tp * plane);
+#pragma unroll
+      for (int tp = 0; tp < 9; ++tp) acc[tp] += v[tp].x, acc[9 + tp] += v[tp].y, acc[18 + tp] += v[tp].z, acc[27 + tp] += v[tp].w;
+    }
+#pragma unroll
+    for (int q = 0; q < 36; ++q) tot[q] += acc[q];
+  }
+  if (vec) {
+#pragma unroll
+    for (int q = 0; q < 9; ++q) reinterpret_cast<float4*>(dwp)[q] = make_float4(tot[4 * q], tot[4 * q + 1], tot[4 * q + 2], tot[4 * q + 3]);
+  } else {
+#pragma unroll
+    for (int q = 0; q < 36; ++q) dwp[q] = tot[q];
+  }
+}
+
+// Layers with MANY slices (the 64-channel layers: a 147-KB weight, 170 slices): a thread walking all slices of its elements
+// is a chain of ~85 dependent memory round trips, the critical path of the whole launch (157 against 84 us).  "Fine" tiles
+// own 16 elements x 9 taps and split the slice range SIXTEEN ways (lane = (slice group, element), 4 groups per wave);
+// the partial sums meet in LDS and are folded in group order, the 144 results leave as one contiguous run.  Only for
+// >= 64 slices: at 8 / 16 slices fine tiles took 195 / 126 us for the same launch (tools/reduce_bench.py).
+constexpr int kWgFineSplits = 64;   // a descriptor is "fine" when any of its sources has at least this many slices
+__device__ __forceinline__ void wgrad_reduce_tile_fine(const WgReduceDesc& d, int tile, float* part /* [16][9][16] */) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, el = lane & 15, sg = wave * 4 + (lane >> 4);
+  const int e0 = tile * 16, e = e0 + el;
+  const bool live = e < d.coci;
+  const size_t plane = (size_t)d.coci, stride = 9 * plane;
+  const int o = threadIdx.x;                          // outputs 0..143 = (element, tap) of this tile
+  const bool oo = o < 144 && e0 * 9 + o < d.coci * 9;
+  float tot = (d.accumulate && oo) ? d.dw[(size_t)e0 * 9 + o] : 0.f;
+  for (int k = 0; k < d.nsrc; ++k) {
+    const int q = (d.splits[k] + 15) >> 4;
+    const int s0 = sg * q, s1 = min(s0 + q, d.splits[k]);
     float acc[9];
 #pragma unroll
     for (int tp = 0; tp < 9; ++tp) acc[tp] = 0.f;
@@ -1733,7 +1815,7 @@ __device__ __forceinline__ void wgrad_reduce_tile(const WgReduceDesc& d, int til
 #pragma unroll
         for (int u = 0; u < 4; ++u)
 #pragma unroll
-          for (int tp = 0; tp < 9; ++tp) v[u][tp] = p[(size_t)(sl + u) * stride + (size_t)tp * d.coci];
+          for (int tp = 0; tp < 9; ++tp) v[u][tp] = p[(size_t)(sl + u) * stride + (size_t)tp * plane];
 #pragma unroll
         for (int u = 0; u < 4; ++u)
 #pragma unroll
@@ -1742,53 +1824,67 @@ __device__ __forceinline__ void wgrad_reduce_tile(const WgReduceDesc& d, int til
       for (; sl < s1; ++sl) {
         float v[9];
 #pragma unroll
-        for (int tp = 0; tp < 9; ++tp) v[tp] = p[(size_t)sl * stride + (size_t)tp * d.coci];
+        for (int tp = 0; tp < 9; ++tp) v[tp] = p[(size_t)sl * stride + (size_t)tp * plane];
 #pragma unroll
         for (int tp = 0; tp < 9; ++tp) acc[tp] += v[tp];
       }
     }
     if (k) __syncthreads();
 #pragma unroll
-    for (int tp = 0; tp < 9; ++tp) part[wave][tp][lane] = acc[tp];
+    for (int tp = 0; tp < 9; ++tp) part[(sg * 9 + tp) * 16 + el] = acc[tp];
     __syncthreads();
+    if (o < 144) {
+      const int el2 = o / 9, tp = o - el2 * 9;
+      float sum = 0.f;
 #pragma unroll
-    for (int j = 0; j < 3; ++j) {
-      const int o = threadIdx.x + j * 256;
-      if (o < 576) {
-        const int el = o / 9, tp = o - el * 9;
-        tot[j] += ((part[0][tp][el] + part[1][tp][el]) + part[2][tp][el]) + part[3][tp][el];
-      }
+      for (int g = 0; g < 16; ++g) sum += part[(g * 9 + tp) * 16 + el2];
+      tot += sum;
     }
   }
-#pragma unroll
-  for (int j = 0; j < 3; ++j) {
-    const int o = threadIdx.x + j * 256;
-    if (o < 576 && e0 * 9 + o < d.coci * 9) d.dw[(size_t)e0 * 9 + o] = tot[j];
-  }
+  if (oo) d.dw[(size_t)e0 * 9 + o] = tot;
 }
+static inline bool wgrad_reduce_fine(const int* splits, int nsrc) {
+  for (int k = 0; k < nsrc; ++k)
+    if (splits[k] >= kWgFineSplits) return true;
+  return false;
+}
+static inline int wgrad_reduce_blocks(int coci, bool fine) { return fine ? cdiv(coci, 16) : cdiv(coci, 1024); }
 
 __global__ __launch_bounds__(256) void wgrad_p_reduce(const float* __restrict__ slab, float* __restrict__ dw, int CoCi,
-                                                     int splits, int accumulate) {
+                                                     int splits, int accumulate, int fine) {
   __shared__ float part[4][9][64];
   WgReduceDesc d;
   d.slab[0] = slab, d.dw = dw, d.splits[0] = splits, d.nsrc = 1, d.coci = CoCi, d.accumulate = accumulate;
-  wgrad_reduce_tile(d, blockIdx.x, part);
+  if (fine) wgrad_reduce_tile_fine(d, blockIdx.x, &part[0][0][0]);
+  else wgrad_reduce_tile(d, blockIdx.x);
 }
 
 // The same reduce for MANY layers in one launch (a backward pass's weight gradients, folded when the pass is over): a
-// device-resident table of descriptors, every layer owns a contiguous block range; a layer whose weight took part in
-// several network passes of the backward lists their slabs in call order.
-__global__ __launch_bounds__(256) void wgrad_p_reduce_many(const WgReduceDesc* __restrict__ tab, int n) {
+// device-resident table of descriptors, every layer owns a contiguous range of tile numbers; a layer whose weight took
+// part in several network passes of the backward lists their slabs in call order.  Persistent blocks: each copies the
+// table into LDS once and walks tiles blockIdx.x, + gridDim.x, ... -- with one block per tile every block began with two
+// dependent global round trips (find the descriptor, load it) in front of a tile that needs one.
+constexpr int kWgMaxDesc = 96;
+__global__ __launch_bounds__(256) void wgrad_p_reduce_many(const WgReduceDesc* __restrict__ tab, int n, int tile0, int tile1) {
   __shared__ float part[4][9][64];
-  __shared__ int s_cnt[4];
-  int mine = 0;
-  for (int i = threadIdx.x; i < n; i += blockDim.x) mine += tab[i].block0 <= (int)blockIdx.x ? 1 : 0;
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) mine += __shfl_down(mine, off);
-  if ((threadIdx.x & 63) == 0) s_cnt[threadIdx.x >> 6] = mine;
+  __shared__ WgReduceDesc s_desc[kWgMaxDesc];
+  {
+    const int* src = reinterpret_cast<const int*>(tab);
+    int* dst = reinterpret_cast<int*>(s_desc);
+    for (int i = threadIdx.x; i < n * (int)(sizeof(WgReduceDesc) / 4); i += blockDim.x) dst[i] = src[i];
+  }
   __syncthreads();
-  const WgReduceDesc d = tab[s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3] - 1];
-  wgrad_reduce_tile(d, (int)blockIdx.x - d.block0, part);
+  int di = 0;
+  for (int t = tile0 + (int)blockIdx.x; t < tile1; t += (int)gridDim.x) {
+    while (di + 1 < n && s_desc[di + 1].block0 <= t) ++di;
+    const WgReduceDesc d = s_desc[di];
+    if (d.fine) {
+      wgrad_reduce_tile_fine(d, t - d.block0, &part[0][0][0]);
+      __syncthreads();                                // `part` is reused by the next tile
+    } else {
+      wgrad_reduce_tile(d, t - d.block0);
+    }
+  }
 }
 
 // Same reduce for SMALL weight tensors with many slices (the 5x5 layers: 4800 elements x 256 slices): one thread
@@ -2701,8 +2797,10 @@ int itcv_conv2d_wgrad_bf16p(const void* xplanes, const void* dyplanes, float* dw
   ITCV_CHECK_LAUNCH("itcv_conv2d_wgrad_bf16p");
   if (accumulate == 2) return 0;     // deferred: the slabs stay in `ws` for itcv_wgrad_reduce_many
   const int coci = Co * Ci;
-  hipLaunchKernelGGL(wgrad_p_reduce, dim3(cdiv(coci, 64)), dim3(256), 0, st, static_cast<const float*>(ws), dw, coci,
-                     p.splits * p.kh, accumulate);
+  const int rsplits = p.splits * p.kh;
+  const bool fine = wgrad_reduce_fine(&rsplits, 1);
+  hipLaunchKernelGGL(wgrad_p_reduce, dim3(wgrad_reduce_blocks(coci, fine)), dim3(256), 0, st, static_cast<const float*>(ws),
+                     dw, coci, rsplits, accumulate, fine ? 1 : 0);
   ITCV_CHECK_LAUNCH("itcv_conv2d_wgrad_bf16p(reduce)");
   return 0;
 }
@@ -2730,13 +2828,18 @@ int itcv_wgrad_reduce_desc(void* host_desc, const float* const* slabs, const int
     d.slab[k] = slabs[k], d.splits[k] = splits[k];
   }
   d.nsrc = nsrc, d.dw = dw, d.coci = Co * Ci, d.accumulate = accumulate ? 1 : 0, d.block0 = block0;
-  d.nblocks = cdiv(d.coci, 64);
+  d.fine = wgrad_reduce_fine(d.splits, nsrc) ? 1 : 0;
+  d.nblocks = wgrad_reduce_blocks(d.coci, d.fine != 0);
   memcpy(host_desc, &d, sizeof(d));
   return d.nblocks;
 }
+int itcv_wgrad_reduce_max_descs(void) { return kWgMaxDesc; }
 int itcv_wgrad_reduce_many(const void* dev_table, int n, int total_blocks, void* stream) {
   ITCV_REQUIRE(dev_table && n > 0 && total_blocks > 0, "itcv_wgrad_reduce_many");
-  hipLaunchKernelGGL(wgrad_p_reduce_many, dim3(total_blocks), dim3(256), 0, S(stream), static_cast<const WgReduceDesc*>(dev_table), n);
+  if (n > kWgMaxDesc) return fail("%s: at most %d descriptors per table (itcv_wgrad_reduce_max_descs)", "itcv_wgrad_reduce_many", kWgMaxDesc);
+  const int grid = total_blocks < 2048 ? total_blocks : 2048;            // 8 blocks per CU, persistent
+  hipLaunchKernelGGL(wgrad_p_reduce_many, dim3(grid), dim3(256), 0, S(stream), static_cast<const WgReduceDesc*>(dev_table), n, 0,
+                     total_blocks);
   ITCV_CHECK_LAUNCH("itcv_wgrad_reduce_many");
   return 0;
 }

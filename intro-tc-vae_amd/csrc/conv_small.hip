@@ -160,10 +160,11 @@ __global__ __launch_bounds__(256) void conv_small_cout_planes_kernel(const u32x4
         float v[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-          const int c = hf * 32 + kg * 8 + j, tap = dh * KS + dw;
-          float t = 0.f;
-          if (co < CO) t = DGRAD ? w[((size_t)c * CO + co) * KK + (KK - 1 - tap)] : w[((size_t)co * C + c) * KK + tap];
-          v[j] = t;
+          // unconditional load from a clamped row, then a select: under a branch the compiler keeps the fp16 scale
+          // multiply with the load and the 80 loads of a wave become 80 dependent round trips
+          const int c = hf * 32 + kg * 8 + j, tap = dh * KS + dw, coc = co < CO ? co : 0;
+          const float t = DGRAD ? w[((size_t)c * CO + coc) * KK + (KK - 1 - tap)] : w[((size_t)coc * C + c) * KK + tap];
+          v[j] = co < CO ? t : 0.f;
         }
         u32x4 pl[2];
         split8<2, F16>(v, pl, F16 ? (float)(1 << kWeightScaleLog2) : 1.f);
@@ -174,30 +175,38 @@ __global__ __launch_bounds__(256) void conv_small_cout_planes_kernel(const u32x4
   const float oscale = F16 ? inv_scale_of(reinterpret_cast<const ScaleRec*>(xp + 2 * plane_stride)) * (1.f / (float)(1 << kWeightScaleLog2)) : 1.f;
   const u32x4 zero = {0u, 0u, 0u, 0u};
   // B fragments of one input row: [half][plane], chunk (b, c8 = half*4 + kg, row, wc)
-  auto load_row = [&](int hr, u32x4 (&dst)[2][2]) {
-    const bool ok = col_ok && (unsigned)hr < (unsigned)H;
+  // Every load is unconditional, from a clamped (always valid) pixel, and masked when it is USED: a load under a bounds
+  // check is a branch, and with branches between them the compiler cannot count the loads still in flight (it then
+  // waits for all of them once per trip of the loop).
+  const int wcc = min(max(wc, 0), W - 1);
+  auto load_row = [&](int hr, u32x4 (&dst)[2][2]) -> bool {
+    const int hc = min(max(hr, 0), H - 1);
 #pragma unroll
     for (int hf = 0; hf < 2; ++hf)
 #pragma unroll
       for (int p = 0; p < 2; ++p)
-        dst[hf][p] = ok ? xp[(size_t)p * plane_stride + ((size_t)b * C8 + hf * 4 + kg) * HW + (size_t)hr * W + wc] : zero;
+        dst[hf][p] = xp[(size_t)p * plane_stride + ((size_t)b * C8 + hf * 4 + kg) * HW + (size_t)hc * W + wcc];
+    return col_ok && (unsigned)hr < (unsigned)H;
   };
   f32x4_t acc[5];
 #pragma unroll
   for (int i = 0; i < 5; ++i) acc[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
   const int nrows = min(RB, H - h0);       // output rows of this job
-  // two input rows in flight behind the one being multiplied: a row's 30 MFMAs alone do not cover a global-memory round trip
-  u32x4 cur[2][2], nxt[2][2], nx2[2][2];
-  load_row(h0 - 2, cur);
-  load_row(h0 - 1, nxt);
+  // A ring of five input rows, one slot per unrolled iteration (so the slots are registers with static names and the
+  // compiler's counted vmcnt waits stay exact): four rows are in flight behind the one being multiplied -- a row's 30
+  // MFMAs (~0.25 us) cover an eighth of a global-memory round trip, and with the three rotating buffers of the first
+  // form the copies between them made every third row wait for everything outstanding.
+  u32x4 ring[5][2][2];
+  bool rok[5];
+#pragma unroll
+  for (int q = 0; q < 5; ++q) rok[q] = load_row(h0 - 2 + q, ring[q]);
   float* zt = zs[wv];
   const float bias_l = (bias && lane < 36 && lane / 12 < CO) ? bias[lane / 12] : 0.f;   // the output channel of this lane's fold
   for (int i0 = 0; i0 < nrows + 4; i0 += 5) {
 #pragma unroll
     for (int r = 0; r < 5; ++r) {
-      const int i = i0 + r;                // input row h0 - 2 + i
+      const int i = i0 + r;                // input row h0 - 2 + i sits in ring[r]
       if (i >= nrows + 4) break;
-      load_row(h0 - 2 + i + 2, nx2);
       // output row o = i - kh (kh = 0..4 = dh + 2) takes filter row kh; its accumulator slot is o mod 5
 #pragma unroll
       for (int kh = 0; kh < 5; ++kh) {
@@ -205,13 +214,15 @@ __global__ __launch_bounds__(256) void conv_small_cout_planes_kernel(const u32x4
         f32x4_t c = acc[slot];
 #pragma unroll
         for (int hf = 0; hf < 2; ++hf) {
-          const bf16x8 b0 = __builtin_bit_cast(bf16x8, cur[hf][0]), b1 = __builtin_bit_cast(bf16x8, cur[hf][1]);
+          const bf16x8 b0 = __builtin_bit_cast(bf16x8, rok[r] ? ring[r][hf][0] : zero),
+                       b1 = __builtin_bit_cast(bf16x8, rok[r] ? ring[r][hf][1] : zero);
           c = mma16x16x32<F16>(af[kh][hf][0], b1, c);
           c = mma16x16x32<F16>(af[kh][hf][1], b0, c);
           c = mma16x16x32<F16>(af[kh][hf][0], b0, c);
         }
         acc[slot] = c;
       }
+      rok[r] = load_row(h0 - 2 + i + 5, ring[r]);   // refill the slot with the row five further down
       // output row o = i - 4 is complete (slot (r - 4) mod 5 = (r + 1) mod 5)
       const int o = i - 4, slot_done = (r + 1) % 5;
       if (o >= 0) {
@@ -232,10 +243,6 @@ __global__ __launch_bounds__(256) void conv_small_cout_planes_kernel(const u32x4
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       }
       acc[slot_done] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int hf = 0; hf < 2; ++hf)
-#pragma unroll
-        for (int p = 0; p < 2; ++p) cur[hf][p] = nxt[hf][p], nxt[hf][p] = nx2[hf][p];
     }
   }
 }
@@ -291,11 +298,10 @@ __global__ __launch_bounds__(256, 2) void conv_small_cin_mfma_kernel(const float
       float v[8];
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        const int tap = dh * KS + k_dw[j];
-        float t = 0.f;
-        if (k_dw[j] < KS)
-          t = DGRAD ? w[((size_t)k_ci[j] * M + m) * KK + (KK - 1 - tap)] : w[((size_t)m * CI + k_ci[j]) * KK + tap];
-        v[j] = t;
+        const bool used = k_dw[j] < KS;              // padding slots: load tap 0 of channel 0 and drop it (no branch)
+        const int tap = used ? dh * KS + k_dw[j] : 0, ci = used ? k_ci[j] : 0;
+        const float t = DGRAD ? w[((size_t)ci * M + m) * KK + (KK - 1 - tap)] : w[((size_t)m * CI + ci) * KK + tap];
+        v[j] = used ? t : 0.f;
       }
       u32x4 pl[2];
       split8<2, F16>(v, pl, F16 ? (float)(1 << kWeightScaleLog2) : 1.f);
@@ -315,7 +321,10 @@ __global__ __launch_bounds__(256, 2) void conv_small_cin_mfma_kernel(const float
     const bool rok = (unsigned)hr < (unsigned)H;
     const float* xr = xb + hr * W;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) v[j] = (rok && offj[j] >= 0) ? xr[offj[j]] : 0.f;
+    for (int j = 0; j < 8; ++j) {
+      const float t = (rok && offj[j] >= 0) ? xr[offj[j]] : 0.f;
+      v[j] = t;
+    }
     split8<2, F16>(v, dst, xscale);
   };
   // ring of R = 5 + AHEAD input-row fragments: slot q holds input row h0 - 2 + i with i % R == q; AHEAD = 1 requests the

@@ -61,6 +61,7 @@ SIGNATURES = {
     "itcv_wgrad_reduce_desc_bytes": (sz, []),
     "itcv_wgrad_reduce_desc": (i32, [p, p, p, i32, p, i32, i32, i32, i32]),
     "itcv_wgrad_reduce_many": (i32, [p, i32, i32, p]),
+    "itcv_wgrad_reduce_max_descs": (i32, []),
     "itcv_linear_workspace": (sz, [i32] * 3),
     "itcv_linear_fwd": (i32, [p, p, p, p, i32, i32, i32, p, sz, p]),
     "itcv_linear_dgrad": (i32, [p, p, p, i32, i32, i32, p, sz, p]),
@@ -186,7 +187,7 @@ class _Lib:
     ``*_variant``: integers in, integer out, no device work) memoised: an eager step asks several thousand such
     questions, and a dict hit is ~10x cheaper than a ctypes call."""
 
-    _PURE = ("_supported", "_workspace", "_bytes", "_elems", "_variant", "_stat_tiles", "_slabs")
+    _PURE = ("_supported", "_workspace", "_bytes", "_elems", "_variant", "_stat_tiles", "_slabs", "_max_descs")
 
     def __init__(self, cdll):
         object.__setattr__(self, "_cdll", cdll)

@@ -219,19 +219,20 @@ def test_bn_upsampled_gradient_mode(HF):
 
 def test_pointwise_and_resampling(HF):
     g = torch.Generator().manual_seed(2)
-    x = torch.randn(3, 5, 8, 12, generator=g)
-    for fn, ref in ((lambda t: HF.LeakyReluFn.apply(t, 0.2), lambda t: F.leaky_relu(t, 0.2)),
-                    (HF.SigmoidFn.apply, torch.sigmoid),
-                    (HF.AvgPool2Fn.apply, lambda t: F.avg_pool2d(t, 2)),
-                    (HF.Upsample2Fn.apply, lambda t: F.interpolate(t, scale_factor=2, mode="nearest"))):
-        xr = x.double().requires_grad_(True)
-        yr = ref(xr)
-        dy = torch.randn(*yr.shape, generator=g)
-        yr.backward(dy.double())
-        xd = x.to(dev()).requires_grad_(True)
-        y = fn(xd)
-        y.backward(dy.to(dev()))
-        assert rel_err(y, yr) < 1e-6 and rel_err(xd.grad, xr.grad) < 1e-6
+    for shape in ((3, 5, 8, 12), (2, 3, 4, 6), (40, 64, 16, 16)):   # W % 4 == 0 takes the 4-wide upsample adjoint
+        x = torch.randn(*shape, generator=g)
+        for fn, ref in ((lambda t: HF.LeakyReluFn.apply(t, 0.2), lambda t: F.leaky_relu(t, 0.2)),
+                        (HF.SigmoidFn.apply, torch.sigmoid),
+                        (HF.AvgPool2Fn.apply, lambda t: F.avg_pool2d(t, 2)),
+                        (HF.Upsample2Fn.apply, lambda t: F.interpolate(t, scale_factor=2, mode="nearest"))):
+            xr = x.double().requires_grad_(True)
+            yr = ref(xr)
+            dy = torch.randn(*yr.shape, generator=g)
+            yr.backward(dy.double())
+            xd = x.to(dev()).requires_grad_(True)
+            y = fn(xd)
+            y.backward(dy.to(dev()))
+            assert rel_err(y, yr) < 1e-6 and rel_err(xd.grad, xr.grad) < 1e-6
     a, b = torch.randn(1000, generator=g), torch.randn(1000, generator=g)
     assert rel_err(HF.AddFn.apply(a.to(dev()), b.to(dev())), a + b) == 0
 
