@@ -697,7 +697,7 @@ FwdPlanP2 plan_fwd_p2(int B, int Ci, int H, int W, int Co, int KS, int ns) {
   p.nt = (int)(((long long)B * H * W + p.bn - 1) / p.bn);
   p.bm = Co <= 64 ? 64 : 128;
   // mid-sized layers: 64-row tiles when that fills the chip without split-K and 128-row tiles would not
-  if (p.bm == 128 && cdiv(Co, 128) * p.nt < 192 && cdiv(Co, 64) * p.nt >= 192) p.bm = 64;
+  if (p.bm == 128 && cdiv(Co, 128) * p.nt < 192 && cdiv(Co, 64) * p.nt >= 128) p.bm = 64;
   p.lds = ((size_t)3 * band_taps_per_stage(p.bm, p.bn, lw) * 2 * 4 * p.bm + (size_t)2 * 2 * 4 * p.PXB) * 16;   // [3][G] weight ring + 2 bands
   const size_t stage_bytes = p.bn == 256 ? (size_t)p.bm * (256 + 4) * sizeof(float) : 0;   // the staged epilogue's tile reuses the allocation
   if (p.lds < stage_bytes) p.lds = stage_bytes;

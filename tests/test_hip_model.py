@@ -330,7 +330,9 @@ def test_intro_tc_step_64x64_vs_oracle(math, c2_oracles):
 def test_intro_tc_step_large_images_vs_oracle(math, size, zdim, channels, B):
     """BASELINE configs[2] / configs[4] shapes (128x128x3, z=256; 256x256x3, z=512) at a small batch: layers wider
     than the band / transposing-read kernels take (W > 64) run on the 128-pixel-tile and in-kernel-split forms --
-    same bar as the 64x64 test."""
+    same bar as the 64x64 test.  The gradient-norm diagnostic `L2` of the fp32-class modes is judged against the
+    committed fp64 ground truth (tests/golden/large_images_fp64.json, made by make_large_fp64.py) with the fp32 oracle's
+    own error as the yardstick: at 256x256 the fp32 oracle is 1.1e-4 off fp64 there (the HIP f16x3 step 1.2e-5)."""
     import models
     import ops
     from oracle.network import Net
@@ -351,8 +353,16 @@ def test_intro_tc_step_large_images_vs_oracle(math, size, zdim, channels, B):
     tr = Trainer("intro_tc", Net("conv", state=sd, **cfg), dataset_size=10000, beta_kl=0.5, beta_rec=0.75,
                  beta_neg=512.0, gamma_r=1e-8, clip=100.0, lr=2e-4)
     ref = tr.step(x, draws)
+    import json
+    g64 = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "large_images_fp64.json")))[str(size)]
     for k in ("loss_enc", "loss_dec", "loss_kl", "loss_rec", "L2"):
-        tol = 1e-3 if (k == "L2" and math == "bf16x3") else 1e-4
+        if k != "L2":
+            assert abs(ref[k] - g64[k]) <= 2e-6 * abs(g64[k]), ("fixture / oracle mismatch", k, ref[k], g64[k])
+        if k == "L2" and math != "bf16x3":
+            yard = abs(ref[k] - g64[k])
+            assert abs(d[k] - g64[k]) <= 1.5 * yard + 1e-5 * abs(g64[k]), (k, d[k], ref[k], g64[k])
+            continue
+        tol = 1e-3 if k == "L2" else 1e-4
         assert abs(d[k] - ref[k]) <= tol * abs(ref[k]), (k, d[k], ref[k])
 
 
