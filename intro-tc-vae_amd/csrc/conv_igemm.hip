@@ -251,29 +251,39 @@ __global__ __launch_bounds__(256) void gemm64_kernel(GemmArgs a) {
   const int kt0 = sk * a.ktiles_per_split, kt1 = min(a.ktiles, kt0 + a.ktiles_per_split);
 
   float areg[8], breg[8];
+  // Clamped (always valid) addresses, all 16 loads of a K-tile issued as one group, bounds applied afterwards by selects:
+  // under their bounds checks the loads were 16 branches with a full wait each -- 16 dependent round trips per K-tile.
   auto load_tile = [&](int kt) {
+    const int kb = kt * BK;
+    const float* pa[8];
+    const float* pb[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int k = A_KC ? (t & 31) : (t >> 6) + 4 * i, m = A_KC ? (t >> 5) + 8 * i : (t & 63);
+      pa[i] = a.A + (long long)min(m0 + m, a.M - 1) * a.sam + (long long)min(kb + k, a.K - 1) * a.sak;
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int k = B_KC ? (t & 31) : (t >> 6) + 4 * i, n = B_KC ? (t >> 5) + 8 * i : (t & 63);
+      pb[i] = a.B + (long long)min(kb + k, a.K - 1) * a.sbk + (long long)min(n0 + n, a.N - 1) * a.sbn;
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) areg[i] = *pa[i];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) breg[i] = *pb[i];
+    __builtin_amdgcn_sched_group_barrier(0x020, 16, 0);     // the 16 VMEM reads together, ahead of everything else
+  };
+  auto store_tile = [&](int buf, int kt) {                  // (the bounds are applied here, when the values are first used)
     const int kb = kt * BK;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const int k = A_KC ? (t & 31) : (t >> 6) + 4 * i, m = A_KC ? (t >> 5) + 8 * i : (t & 63);
-      areg[i] = (m0 + m < a.M && kb + k < a.K) ? a.A[(long long)(m0 + m) * a.sam + (long long)(kb + k) * a.sak] : 0.f;
+      As[buf][k * PA + m] = (m0 + m < a.M && kb + k < a.K) ? areg[i] : 0.f;
     }
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const int k = B_KC ? (t & 31) : (t >> 6) + 4 * i, n = B_KC ? (t >> 5) + 8 * i : (t & 63);
-      breg[i] = (n0 + n < a.N && kb + k < a.K) ? a.B[(long long)(kb + k) * a.sbk + (long long)(n0 + n) * a.sbn] : 0.f;
-    }
-  };
-  auto store_tile = [&](int buf) {
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int k = A_KC ? (t & 31) : (t >> 6) + 4 * i, m = A_KC ? (t >> 5) + 8 * i : (t & 63);
-      As[buf][k * PA + m] = areg[i];
-    }
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int k = B_KC ? (t & 31) : (t >> 6) + 4 * i, n = B_KC ? (t >> 5) + 8 * i : (t & 63);
-      Bs[buf][k * PB + n] = breg[i];
+      Bs[buf][k * PB + n] = (n0 + n < a.N && kb + k < a.K) ? breg[i] : 0.f;
     }
   };
   f32x16 acc[1][1];
@@ -281,14 +291,14 @@ __global__ __launch_bounds__(256) void gemm64_kernel(GemmArgs a) {
   for (int r = 0; r < 16; ++r) acc[0][0][r] = 0.f;
   if (kt0 < kt1) {
     load_tile(kt0);
-    store_tile(0);
+    store_tile(0, kt0);
     __syncthreads();
     int cur = 0;
     for (int kt = kt0; kt < kt1; ++kt) {
       const bool more = kt + 1 < kt1;
       if (more) load_tile(kt + 1);
       mfma_tile<BK, PA, PB, 1, 1>(&As[cur][half * PA + wm * 32 + l31], &Bs[cur][half * PB + wn * 32 + l31], acc);
-      if (more) store_tile(cur ^ 1);
+      if (more) store_tile(cur ^ 1, kt + 1);
       __syncthreads();
       cur ^= 1;
     }
