@@ -53,11 +53,17 @@ int itcv_set_option(const char* name, int value) {
     itcv::g_opt.band_persist_blocks = value;
     return 0;
   }
+  if (!strcmp(name, "wgrad_m16")) {
+    if (value != 0 && value != 1) return itcv::fail("%s: wgrad_m16 takes 0 or 1 (got %lld)", "itcv_set_option", value);
+    itcv::g_opt.wgrad_m16 = value;
+    return 0;
+  }
   return itcv::fail("%s: unknown option", "itcv_set_option");
 }
 int itcv_get_option(const char* name) {
   if (name && !strcmp(name, "band_m16")) return itcv::g_opt.band_m16;
   if (name && !strcmp(name, "band_persist_blocks")) return itcv::g_opt.band_persist_blocks;
+  if (name && !strcmp(name, "wgrad_m16")) return itcv::g_opt.wgrad_m16;
   return -1;
 }
 const char* itcv_last_error(void) { return itcv::g_err; }

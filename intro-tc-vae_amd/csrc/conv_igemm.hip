@@ -1348,7 +1348,10 @@ __device__ __forceinline__ void tr_read8(bf16x8& dst, uint32_t addr0, uint32_t a
 
 // KH = 2 (the 64 x 64 tile): the eight MFMA waves are two groups of four that take alternate halves of a step's four
 // 16-pixel k-steps and keep separate slabs (slab index split*KH + kh) -- the tile is too small for eight waves otherwise.
-template <int LOG2W, bool UP2, int BM, int BN, int NST, int NLW, int KH = 1, bool F16 = false>
+// M16: the products are v_mfma_f32_16x16x32 (a 32 x 32 wave tile = 2 x 2 blocks, k-steps of 32 pixels: the four 16-lane
+// groups of a transposing read take the four 8-pixel quarters of a k-step instead of two halves of a 16-pixel one) -- same
+// LDS reads and MFMA cycles per FLOP as 32x32x16; the chip holds a higher clock on this shape (band kernels: +5-8 %).
+template <int LOG2W, bool UP2, int BM, int BN, int NST, int NLW, int KH = 1, bool F16 = false, bool M16 = false>
 __global__ __launch_bounds__(512 + 64 * NLW) void conv_wgrad_bf16p_kernel(WgradArgsP a) {
   constexpr int W = 1 << LOG2W, NR = 64 >> LOG2W, WP = W + 2, NP = NR * WP;   // band: NR rows x (W+2) columns
   constexpr int PXA = 68, PXB = ((NP + 11) / 16) * 16 + 4;                     // row strides = 4 (mod 16) chunks: conflict-free tr reads
@@ -1456,6 +1459,133 @@ __global__ __launch_bounds__(512 + 64 * NLW) void conv_wgrad_bf16p_kernel(WgradA
   const int wm = w8 / WNn, wn = w8 % WNn;
   const int G = lane >> 4, i16 = lane & 15, q = i16 >> 2, pp = i16 & 3, half = G >> 1, rb = G & 1;
   const int l31 = lane & 31;
+  if constexpr (M16) {
+    typedef float f32x4m __attribute__((ext_vector_type(4)));
+    constexpr int KP32 = 2 / KH;                      // 32-pixel k-steps per wave and 64-pixel step
+    f32x4m acc[3][TNw][2][2];                         // [tap][32-column tile][16-row block][16-column block]
+#pragma unroll
+    for (int tp = 0; tp < 3; ++tp)
+#pragma unroll
+      for (int j = 0; j < TNw; ++j)
+#pragma unroll
+        for (int bi = 0; bi < 2; ++bi)
+#pragma unroll
+          for (int bj = 0; bj < 2; ++bj) acc[tp][j][bi][bj] = f32x4m{0.f, 0.f, 0.f, 0.f};
+    if (s0 < s1) {
+      // this lane's transposed reads: 16-lane group G takes pixels 8G .. 8G+7 of the k-step; (q, pp) as above
+      const uint32_t aoff = (uint32_t)(((4 * wm + (pp >> 1)) * PXA + G * 8 + q) * 16 + (pp & 1) * 8);
+      const uint32_t boff = (uint32_t)((ASZ + (4 * wn * TNw + (pp >> 1)) * PXB) * 16 + (pp & 1) * 8);
+      uint32_t hidx[2 * KP32];                        // band index of pixel k = kk*32 + G*8 + s*4 + q, centre tap
+#pragma unroll
+      for (int u = 0; u < 2 * KP32; ++u) {
+        const int k = ((u >> 1) + kh * KP32) * 32 + G * 8 + (u & 1) * 4 + q;
+        hidx[u] = (uint32_t)(((k >> LOG2W) * WP + (k & (W - 1)) + 1) * 16);
+      }
+      __builtin_amdgcn_s_barrier();
+      int stage = 0;
+      for (int st = s0; st < s1; ++st) {
+        const uint32_t sb = smem_base + (uint32_t)(stage * SSZ) * 16u;
+        if constexpr (TNw == 1) {
+          // software pipeline over the step's KP32 * 6 units (k-step, tap, column block): the two B fragments of unit u+1
+          // (and the four A fragments of the next k-step) are requested before the six MFMAs of unit u
+          bf16x8 af[2][2][2], bfr[2][2];
+          auto fetch_a = [&](int kk, int kb) {
+#pragma unroll
+            for (int bi = 0; bi < 2; ++bi)
+#pragma unroll
+              for (int pl = 0; pl < 2; ++pl) {
+                const uint32_t ad = sb + aoff + (uint32_t)((pl * ACH + 2 * bi) * PXA * 16 + (kh * KP32 + kk) * 512);
+                tr_read8(af[kb][bi][pl], ad, ad + 64);
+              }
+          };
+          auto fetch_b = [&](int u, int ub) {
+            const int kk = u / 6, tp = (u % 6) >> 1, bj = u & 1;
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) {
+              const uint32_t bd = sb + boff + (uint32_t)((pl * BCH + 2 * bj) * PXB * 16 + (tp - 1) * 16);
+              tr_read8(bfr[ub][pl], bd + hidx[kk * 2], bd + hidx[kk * 2 + 1]);
+            }
+          };
+          constexpr int NU = KP32 * 6;
+          fetch_a(0, 0);
+          fetch_b(0, 0);
+#pragma unroll
+          for (int u = 0; u < NU; ++u) {
+            const int kk = u / 6, tp = (u % 6) >> 1, bj = u & 1, ub = u & 1, kb = kk & 1;
+            if (u + 1 < NU) {
+              if ((u + 1) % 6 == 0) fetch_a(kk + 1, kb ^ 1);
+              fetch_b(u + 1, ub ^ 1);
+            }
+#pragma unroll
+            for (int bi = 0; bi < 2; ++bi) {
+              f32x4m c = acc[tp][0][bi][bj];
+              c = mma16x16x32<F16>(af[kb][bi][0], bfr[ub][1], c);
+              c = mma16x16x32<F16>(af[kb][bi][1], bfr[ub][0], c);
+              c = mma16x16x32<F16>(af[kb][bi][0], bfr[ub][0], c);
+              acc[tp][0][bi][bj] = c;
+            }
+          }
+        } else {
+#pragma unroll
+        for (int kk = 0; kk < KP32; ++kk) {
+          bf16x8 af[2][2];
+#pragma unroll
+          for (int bi = 0; bi < 2; ++bi)
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) {
+              const uint32_t ad = sb + aoff + (uint32_t)((pl * ACH + 2 * bi) * PXA * 16 + (kh * KP32 + kk) * 512);
+              tr_read8(af[bi][pl], ad, ad + 64);
+            }
+#pragma unroll
+          for (int tp = 0; tp < 3; ++tp)
+#pragma unroll
+            for (int j = 0; j < TNw; ++j)
+#pragma unroll
+              for (int bj = 0; bj < 2; ++bj) {
+                bf16x8 bfr[2];
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl) {
+                  const uint32_t bd = sb + boff + (uint32_t)((pl * BCH + 4 * j + 2 * bj) * PXB * 16 + (tp - 1) * 16);
+                  tr_read8(bfr[pl], bd + hidx[kk * 2], bd + hidx[kk * 2 + 1]);
+                }
+#pragma unroll
+                for (int bi = 0; bi < 2; ++bi) {
+                  f32x4m c = acc[tp][j][bi][bj];
+                  c = mma16x16x32<F16>(af[bi][0], bfr[1], c);
+                  c = mma16x16x32<F16>(af[bi][1], bfr[0], c);
+                  c = mma16x16x32<F16>(af[bi][0], bfr[0], c);
+                  acc[tp][j][bi][bj] = c;
+                }
+              }
+        }
+        }
+        if (++stage == NST) stage = 0;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+      }
+    }
+    // slab[split][tap][co][ci]: lane (G, i16) holds rows 4G .. 4G+3 and column i16 of every 16 x 16 block
+    const float oscale = F16 ? inv_scale_of(a.xscale) * inv_scale_of(a.dyscale) : 1.f;
+#pragma unroll
+    for (int j = 0; j < TNw; ++j)
+#pragma unroll
+      for (int bj = 0; bj < 2; ++bj) {
+        const int ci = ci0 + 32 * (wn * TNw + j) + 16 * bj + i16;
+        if (ci >= a.Ci) continue;
+#pragma unroll
+        for (int tp = 0; tp < 3; ++tp) {
+          float* out = a.slab + ((size_t)((split * KH + kh) * 9 + dhi * 3 + tp) * a.Co) * a.Ci + ci;
+#pragma unroll
+          for (int bi = 0; bi < 2; ++bi)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int co = co0 + 32 * wm + 16 * bi + 4 * G + r;
+              if (co < a.Co) out[(size_t)co * a.Ci] = F16 ? acc[tp][j][bi][bj][r] * oscale : acc[tp][j][bi][bj][r];
+            }
+        }
+      }
+    return;
+  }
   f32x16 acc[3][TNw];
 #pragma unroll
   for (int tp = 0; tp < 3; ++tp)
@@ -2217,6 +2347,19 @@ static void launch_wgrad_p_cfg(const WgradArgsP& a, int blocks, hipStream_t st) 
   constexpr size_t lds = NST * stage_bytes;
   if constexpr (lds <= 160 * 1024) {
     constexpr int NLW = 4;   // loader waves (eight were measured no faster, and spill in the 128 x 128 form)
+    // 16x16x32 by default (tools/wgrad_m16_bench.py, c2 shapes, f16x3: -7.8 % summed over the layers; +14 % on the
+    // 128-column tiles, +9 % on the 4x4 layers, within -3.5 % on two shapes)
+    const bool m16 = g_opt.wgrad_m16 != 0;
+    if (m16) {
+      auto kern = conv_wgrad_bf16p_kernel<LOG2W, UP2, BM, BN, NST, NLW, KH, F16, true>;
+      static bool attr_set = false;
+      if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+      }
+      launch_timed(kern, dim3(blocks), dim3(512 + 64 * NLW), lds, st, a);
+      return;
+    }
     auto kern = conv_wgrad_bf16p_kernel<LOG2W, UP2, BM, BN, NST, NLW, KH, F16>;
     static bool attr_set = false;
     if (!attr_set) {

@@ -110,9 +110,11 @@ struct BandMfma<true, F16> {
 //                        written for that accumulator layout).
 //   band_persist_blocks  256 (default): block count of the persistent band kernel, used when a launch has more tiles than
 //                        that; 0: one tile per block always.  Any value gives bit-identical results (tests).
+//   wgrad_m16            1 (default): v_mfma_f32_16x16x32 in the planes weight-gradient kernel; 0: 32x32x16.
 struct Options {
   int band_m16 = 1;
   int band_persist_blocks = 256;
+  int wgrad_m16 = 1;
 };
 extern Options g_opt;
 inline int band_m16() { return g_opt.band_m16; }

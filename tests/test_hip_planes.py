@@ -130,7 +130,8 @@ def test_persistent_band_kernel_vs_one_tile_kernel_and_fp64(HF, case):
 def test_option_api_validates(HF):
     """itcv_set_option: unknown names and out-of-range values are refused; nothing is read from the environment."""
     from hipvae import abi
-    for name, value in (("band_persist_blocks", -1), ("band_persist_blocks", 4096), ("band_m16", 2), ("no_such_option", 1)):
+    for name, value in (("band_persist_blocks", -1), ("band_persist_blocks", 4096), ("band_m16", 2), ("wgrad_m16", 2),
+                        ("no_such_option", 1)):
         with pytest.raises(RuntimeError):
             HF.set_option(name, value)
     assert HF.get_option("no_such_option") == -1
@@ -243,6 +244,9 @@ def test_f16_planes_weight_gradient(HF, case):
     dw = HF.conv_wgrad_planes(xp, dyp, B, Ci, H, W, Co, 3, up2, ns=4)
     assert rel_err(dw, ref) < 1.5e-6
     assert torch.equal(dw, HF.conv_wgrad_planes(xp, dyp, B, Ci, H, W, Co, 3, up2, ns=4))
+    for m16 in (0, 1):
+        with HF.option_scope("wgrad_m16", m16):
+            assert rel_err(HF.conv_wgrad_planes(xp, dyp, B, Ci, H, W, Co, 3, up2, ns=4), ref) < 1.5e-6, m16
 
 
 @pytest.mark.parametrize("shape,pool,groups", [((4, 64, 32, 32), False, 1), ((4, 64, 32, 32), True, 2), ((8, 128, 16, 16), False, 2),
@@ -352,6 +356,12 @@ def test_planes_weight_gradient(HF, case):
     assert rel_err(acc, 2 * ref) < 5e-5
     again = HF.conv_wgrad_planes(xp, dyp, B, Ci, H, W, Co, 3, up2)
     assert torch.equal(dw, again)   # split-K slabs are reduced in a fixed order
+    # both inner products in every tile form: same values to rounding, same bar vs fp64
+    for m16 in (0, 1):
+        with HF.option_scope("wgrad_m16", m16):
+            alt = HF.conv_wgrad_planes(xp, dyp, B, Ci, H, W, Co, 3, up2)
+        assert rel_err(alt, ref) < 5e-5 and rel_err(alt, dw) < 2e-6, m16
+    assert HF.get_option("wgrad_m16") == 1
 
 
 def test_deferred_weight_gradient_reduces_equal_immediate_ones(HF):
