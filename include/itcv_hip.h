@@ -36,6 +36,7 @@ const char* itcv_last_error(void);
  *   "band_persist_blocks"  256 (default): blocks of the persistent band kernel (used when a launch has more tiles);
  *                          0: one tile per block; range 0..1024
  *   "wgrad_m16"            1 (default): v_mfma_f32_16x16x32 in itcv_conv2d_wgrad_bf16p; 0: 32x32x16 (equal to rounding)
+ *   "planes_mfma_waves"    8 (default) or 4: MFMA waves of the 128 x 128 tile of the 128-pixel planes kernel (bit-identical)
  * itcv_set_option returns non-zero for an unknown name or a value out of range; itcv_get_option returns -1 for an unknown name. */
 int itcv_set_option(const char* name, int value);
 int itcv_get_option(const char* name);

@@ -58,12 +58,18 @@ int itcv_set_option(const char* name, int value) {
     itcv::g_opt.wgrad_m16 = value;
     return 0;
   }
+  if (!strcmp(name, "planes_mfma_waves")) {
+    if (value != 4 && value != 8) return itcv::fail("%s: planes_mfma_waves takes 4 or 8 (got %lld)", "itcv_set_option", value);
+    itcv::g_opt.planes_mfma_waves = value;
+    return 0;
+  }
   return itcv::fail("%s: unknown option", "itcv_set_option");
 }
 int itcv_get_option(const char* name) {
   if (name && !strcmp(name, "band_m16")) return itcv::g_opt.band_m16;
   if (name && !strcmp(name, "band_persist_blocks")) return itcv::g_opt.band_persist_blocks;
   if (name && !strcmp(name, "wgrad_m16")) return itcv::g_opt.wgrad_m16;
+  if (name && !strcmp(name, "planes_mfma_waves")) return itcv::g_opt.planes_mfma_waves;
   return -1;
 }
 const char* itcv_last_error(void) { return itcv::g_err; }

@@ -620,13 +620,14 @@ struct ConvArgsP {
 #endif
 };
 
+// WM x WN MFMA waves (4, or 8 = two per SIMD: one fills the other's barrier / LDS-latency bubbles) + 4 loader waves.
 template <int KS, int BM, int BN, int WM, int WN, bool UP2, int NS, int NSTAGE, bool M16 = false, bool F16 = false>
-__global__ __launch_bounds__(512) void conv_fwd_bf16p_kernel(ConvArgsP a) {
+__global__ __launch_bounds__(64 * (WM * WN + 4)) void conv_fwd_bf16p_kernel(ConvArgsP a) {
   static_assert(!M16 || NS == 2, "the 16x16x32 form is written for two planes");
   static_assert(!F16 || M16, "the fp16 planes form uses the 16x16x32 products");
-  constexpr int BK = 32, KC = BK / 8, P = KS / 2, KKc = KS * KS;
+  constexpr int BK = 32, KC = BK / 8, P = KS / 2, KKc = KS * KS, NMW = WM * WN;
   constexpr int WTM = BM / WM, WTN = BN / WN;
-  static_assert(WM * WN == 4 && (BN == 128 || BN == 256) && (BM == 64 || BM == 128), "tile / wave layout");
+  static_assert((NMW == 4 || NMW == 8) && (BN == 128 || BN == 256) && (BM == 64 || BM == 128), "tile / wave layout");
   constexpr int ASZ = NS * KC * BM, BSZ = NS * KC * BN, SSZ = ASZ + BSZ;   // 16-byte chunks per stage
   extern __shared__ u32x4 smem[];
 
@@ -644,9 +645,9 @@ __global__ __launch_bounds__(512) void conv_fwd_bf16p_kernel(ConvArgsP a) {
   if (nk <= 0) return;
   const uint32_t smem_base = lds_addr(smem);
 
-  if (wid >= 4) {
+  if (wid >= NMW) {
     // ------------------------------------------------------------------ loaders
-    const int lw = wid - 4;
+    const int lw = wid - NMW;
     constexpr int NPA = BM / 64, NPB = BN / 64;            // 1-KiB pieces per (plane, k-chunk) row
     constexpr int PA = NS * KC * NPA / 4, PB = NS * KC * NPB / 4, PT = PA + PB;   // pieces per wave per tile
     static_assert((NS * KC * NPA) % 4 == 0 && (NPB == 2 || NPB == 4), "piece split");
@@ -2273,7 +2274,7 @@ template <int KS, int BM, int BN, int WM, int WN, bool UP2, int NS, int NSTAGE, 
 static void launch_fwd_p_cfg(const ConvArgsP& a, int splits, hipStream_t st) {
   constexpr size_t lds = (size_t)NSTAGE * NS * 4 * (BM + BN) * 16;
   static_assert(lds <= 160 * 1024, "LDS ring too large");
-  dim3 grid(cdiv(a.nt, 8) * 8 * a.mt, splits), blk(512);
+  dim3 grid(cdiv(a.nt, 8) * 8 * a.mt, splits), blk(64 * (WM * WN + 4));
   if constexpr (NS == 2) {
     if (F16 || band_m16()) {
       auto k16 = conv_fwd_bf16p_kernel<KS, BM, BN, WM, WN, UP2, NS, NSTAGE, true, F16>;
@@ -2301,6 +2302,11 @@ static void launch_fwd_p_st(const ConvArgsP& a, int bm, int splits, int up2, hip
   if (bm == 64) {
     if (up2) launch_fwd_p_cfg<KS, 64, 256, 1, 4, true, NS, NSTAGE, F16>(a, splits, st);
     else launch_fwd_p_cfg<KS, 64, 256, 1, 4, false, NS, NSTAGE, F16>(a, splits, st);
+  } else if (NS == 2 && g_opt.planes_mfma_waves == 8 && (F16 || band_m16())) {
+    if constexpr (NS == 2) {   // eight MFMA waves of 64 x 32 (16x16x32 form)
+      if (up2) launch_fwd_p_cfg<KS, 128, 128, 2, 4, true, NS, NSTAGE, F16>(a, splits, st);
+      else launch_fwd_p_cfg<KS, 128, 128, 2, 4, false, NS, NSTAGE, F16>(a, splits, st);
+    }
   } else {
     if (up2) launch_fwd_p_cfg<KS, 128, 128, 2, 2, true, NS, NSTAGE, F16>(a, splits, st);
     else launch_fwd_p_cfg<KS, 128, 128, 2, 2, false, NS, NSTAGE, F16>(a, splits, st);

@@ -111,10 +111,14 @@ struct BandMfma<true, F16> {
 //   band_persist_blocks  256 (default): block count of the persistent band kernel, used when a launch has more tiles than
 //                        that; 0: one tile per block always.  Any value gives bit-identical results (tests).
 //   wgrad_m16            1 (default): v_mfma_f32_16x16x32 in the planes weight-gradient kernel; 0: 32x32x16.
+//   planes_mfma_waves    8 (default): the 128 x 128 tile of the 128-pixel planes kernel (the 4x4 layers) runs eight MFMA waves
+//                        of 64 x 32 (two per SIMD: one fills the other's barrier / LDS-latency bubbles) instead of four of
+//                        64 x 64: bit-identical, 1.5-8 % faster on the 4x4 layers (tools/planes_waves_bench.py).
 struct Options {
   int band_m16 = 1;
   int band_persist_blocks = 256;
   int wgrad_m16 = 1;
+  int planes_mfma_waves = 8;   // MFMA waves of the 128 x 128 tile of the 128-pixel planes kernel (the 4x4 layers): 4 or 8
 };
 extern Options g_opt;
 inline int band_m16() { return g_opt.band_m16; }

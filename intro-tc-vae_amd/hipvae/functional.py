@@ -24,7 +24,7 @@ F32 = torch.float32
 def set_option(name, value):
     """Launch-shape options of the library (include/itcv_hip.h: itcv_set_option): 'band_m16' (0/1),
     'band_persist_blocks' (0 = one tile per block, else the persistent kernel's block count), 'wgrad_m16' (0 / 1 =
-    32x32x16 / 16x16x32 products in the planes weight gradient).  Validated by the library."""
+    32x32x16 / 16x16x32 products in the planes weight gradient), 'planes_mfma_waves' (4 / 8).  Validated by the library."""
     call("itcv_set_option", name.encode(), int(value))
 
 

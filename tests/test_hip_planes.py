@@ -127,15 +127,38 @@ def test_persistent_band_kernel_vs_one_tile_kernel_and_fp64(HF, case):
     assert rel_err(y3, y) < 2e-6 and rel_err(dx3, dx) < 2e-6 and not torch.equal(y3, y)
 
 
+@pytest.mark.parametrize("case", [(4, 128, 4, 4, 256, False), (32, 512, 4, 4, 256, False), (16, 256, 4, 4, 544, True)])
+@pytest.mark.parametrize("math", ["bf16x3", "f16x3"])
+def test_planes_kernel_four_and_eight_mfma_waves_bit_identical(HF, case, math):
+    """The 128 x 128 tile of the 128-pixel planes kernel (W = 4 layers, split-K included) with eight MFMA waves of 64 x 32
+    (default) and with four of 64 x 64: the same K order, bit-identical forward and data-gradient."""
+    B, Ci, H, W, Co, up2 = case
+    ns = {"bf16x3": 2, "f16x3": 4}[math]
+    g = torch.Generator().manual_seed(sum(case[:5]))
+    hs, ws = (H // 2, W // 2) if up2 else (H, W)
+    x = torch.randn(B, Ci, hs, ws, generator=g).to(dev())
+    w = (torch.randn(Co, Ci, 3, 3, generator=g) / (Ci * 9) ** 0.5).to(dev())
+    dy = torch.randn(B, Co, H, W, generator=g).to(dev())
+    out = {}
+    with HF.conv_math_scope(math):
+        for nw in (8, 4):
+            with HF.option_scope("planes_mfma_waves", nw):
+                y = HF.conv_apply_planes(HF.split_planes(x, ns), w, w, 0, None, B, Ci, H, W, Co, 3, up2, ns)
+                dx = HF.conv_apply_planes(HF.split_planes(dy, ns, gradient=True), w, w, 1, None, B, Co, H, W, Ci, 3, False, ns)
+            out[nw] = (y, dx)
+    assert torch.equal(out[8][0], out[4][0]) and torch.equal(out[8][1], out[4][1])
+
+
 def test_option_api_validates(HF):
     """itcv_set_option: unknown names and out-of-range values are refused; nothing is read from the environment."""
     from hipvae import abi
     for name, value in (("band_persist_blocks", -1), ("band_persist_blocks", 4096), ("band_m16", 2), ("wgrad_m16", 2),
-                        ("no_such_option", 1)):
+                        ("planes_mfma_waves", 6), ("no_such_option", 1)):
         with pytest.raises(RuntimeError):
             HF.set_option(name, value)
     assert HF.get_option("no_such_option") == -1
     assert HF.get_option("band_m16") == 1 and HF.get_option("band_persist_blocks") == 256
+    assert HF.get_option("wgrad_m16") == 1 and HF.get_option("planes_mfma_waves") == 8
 
 
 def test_batched_bn_act_conv_chain_vs_fp64(HF):
